@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: voxels/sec of the INR fit on a synthetic 128^3 volume (x4 up-scaling config).
+
+One "step" = one full-batch fit step (forward + MSE + backward + Adam) over the N = 64*64*128 = 524,288
+LR coordinates of the volume (LR = vol[::2, ::2, :]); Siren(256,512,3,1), Fourier
+features 128 x sigma 0.5, Adam 1e-4 -- the loop of superresDWI.py:132-138.  Inputs (feature matrix,
+targets, weights) are resident in HBM before the timed region.  `value` = coordinate-steps per second
+summed over all ranks (each rank fits its own volume: weak scaling, no data-path collective; the
+only collective is the final all_gather of metric records over RCCL).
+
+Extra objects on the JSON line: `roofline` (fp32-MFMA GEMM kernel, HIP-event timed inside the timed
+region), `cpu_baseline` (the torch-CPU port of the reference loop on a bounded row sample), `recon`
+(dense x4 re-sampling of the 256x256x128 grid) and `quality` (cfg-1 real-slice fit PSNR).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+IN_F, HIDDEN, LAYERS, OUT_F = 256, 512, 3, 1
+SIDE = 128
+
+
+def flops_per_coord():
+    fwd = 2 * IN_F * HIDDEN + LAYERS * 2 * HIDDEN * HIDDEN          # sine-layer GEMMs (head is a row-dot)
+    dw = fwd                                                         # param-grad GEMMs, same shapes
+    dx = LAYERS * 2 * HIDDEN * HIDDEN                                # input-grad GEMMs (none for layer 0)
+    return fwd, dx, dw
+
+
+def cpu_baseline(n_sample, steps, B_np, vol):
+    """Torch-CPU port of the reference loop on the first `n_sample` LR rows of the same workload."""
+    from oracle import torch_port as P
+    torch.manual_seed(0)
+    net = P.PortSiren(IN_F, HIDDEN, LAYERS, OUT_F)
+    lr = vol[::2, ::2, :]
+    grid = P.port_mgrid(lr.shape)[:n_sample]
+    x = P.port_input_mapping(grid, torch.from_numpy(B_np))
+    t = torch.from_numpy(np.ascontiguousarray(lr).reshape(-1, 1)[:n_sample])
+    opt = torch.optim.Adam(lr=1e-4, params=list(net.parameters()))
+    P.port_fit(net, x, t, 1, optimizer=opt)                          # warm-up
+    t0 = time.perf_counter()
+    P.port_fit(net, x, t, steps, optimizer=opt)
+    dt = time.perf_counter() - t0
+    return {"value": n_sample * steps / dt, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {n_sample} of 524288 LR rows of the synthetic 128^3 fit, {steps} steps after 1 warm-up, "
+                      f"torch {torch.__version__} CPU ({os.cpu_count()} logical CPUs visible)",
+            "seconds": dt}
+
+
+def cfg1_quality(inr, steps=2500):
+    """Config 1 on the committed real slice: fit the 64x64 LR of pat07 slice 11, PSNR of the x2 recon vs HR."""
+    path = os.path.join(ROOT, "tests", "golden", "pat07_slice11.npz")
+    if not os.path.exists(path):
+        return None
+    from oracle import inr_oracle as O
+    from oracle import torch_port as P
+    z = np.load(path)
+    hr, lr = z["hr"], z["lr"]
+    B = torch.from_numpy(P.fourier_matrix(2)).cuda()
+    torch.manual_seed(0)
+    net = inr.Siren(IN_F, HIDDEN, LAYERS, OUT_F).cuda()
+    ds = inr.ImageFitting_set([lr])
+    x = inr.input_mapping(ds.coords[0], B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fitter, losses = inr.fit_siren(net, x, ds.pixels[0], steps, lr=1e-4)
+    rec = inr.reconstruct(net, (128, 128), B)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"config": "pat07 slice 11, 64x64 LR -> 128x128, 2500 steps, seed 0", "psnr_db": O.psnr(hr, rec.cpu().numpy()),
+            "reference_cpu_psnr_db_seeds0to3": [32.59, 32.29, 32.37, 32.21], "final_loss": float(losses[-1]),
+            "fit_plus_recon_seconds": dt, "train_voxels_per_s": lr.size * steps / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip recon/quality legs (profiling runs)")
+    ap.add_argument("--cpu-sample", type=int, default=65536)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mri_super_resolution_amd as inr
+    from mri_super_resolution_amd import dist as inr_dist
+    from mri_super_resolution_amd import ops
+    from oracle import torch_port as P
+
+    # ---- workload: one synthetic 128^3 volume per rank (seeded by rank), resident in HBM -------------
+    vol = P.synthetic_volume(SIDE, seed=rank)
+    lr = np.ascontiguousarray(vol[::2, ::2, :])
+    n_lr = lr.size
+    B_np = P.fourier_matrix(3)
+    B = torch.from_numpy(B_np).cuda()
+    torch.manual_seed(0)
+    net = inr.Siren(IN_F, HIDDEN, LAYERS, OUT_F).cuda()
+    x = ops.grid_fourier_map(lr.shape, B)                           # [N, 256] feature matrix, built once per fit
+    target = torch.from_numpy(lr.reshape(-1, 1)).cuda()
+    fitter = inr.SirenFitter(net, lr=1e-4)
+
+    fitter.step(x, target, n_steps=args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    losses = fitter.step(x, target, n_steps=args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+
+    # ---- final metric gather (the only collective on the path) --------------------------------------
+    record = {"rank": rank, "n": n_lr, "steps": args.steps, "seconds": dt, "final_loss": float(losses[-1])}
+    records = inr_dist.gather_records(record)
+    dt_max = max(r["seconds"] for r in records)
+    total_units = sum(r["n"] * r["steps"] for r in records)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    fwd_f, dx_f, dw_f = flops_per_coord()
+    classes = {}
+    tot_ms, tot_flop, tot_launch = 0.0, 0.0, 0
+    for kc, (name, fl) in enumerate((("gemm_forward", fwd_f), ("gemm_input_grad", dx_f), ("gemm_param_grad", dw_f))):
+        launches, ms = ops.prof_read(kc)
+        flop = fl * n_lr * args.steps
+        classes[name] = {"launches": launches, "avg_ms": ms / max(launches, 1), "tflops": flop / (ms * 1e-3) / 1e12}
+        tot_ms += ms
+        tot_flop += flop
+        tot_launch += launches
+    other_launches, other_ms = ops.prof_read(3)
+    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "launches": tot_launch, "avg_launch_ms": tot_ms / max(tot_launch, 1),
+                "gemm_ms_per_step": tot_ms / args.steps, "other_kernels_ms_per_step": other_ms / args.steps,
+                "per_class": classes}
+    ops.prof_reset()
+
+    out = {"metric": "voxels/sec per INR fit (128^3, x4 upscale): train coordinate-steps/s",
+           "value": total_units / dt_max, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "synthetic 128^3 volume, LR 64x64x128 (N=524288 coords) -> x4 grid 256x256x128; "
+                                  "Siren(256,512,3,1) + 128 Fourier features, Adam 1e-4, full-batch MSE",
+                      "per_gpu_rows": n_lr, "parallelism": f"{world} independent fits (one volume per GPU)"},
+           "roofline": roofline}
+
+    if not args.no_extras:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rec = inr.reconstruct(net, (2 * SIDE, 2 * SIDE, SIDE), B)
+        torch.cuda.synchronize()
+        t_rec = time.perf_counter() - t0
+        out["recon"] = {"grid": [2 * SIDE, 2 * SIDE, SIDE], "voxels_per_s": rec.numel() / t_rec, "seconds": t_rec,
+                        "tflops": rec.numel() * (fwd_f + 2 * HIDDEN) / t_rec / 1e12}
+        del rec
+        fitter.release_workspace()
+        out["quality"] = cfg1_quality(inr)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, B_np, vol)
+        out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

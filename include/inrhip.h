@@ -1,0 +1,172 @@
+/*
+ * inrhip.h -- C ABI of libinrhip.so: the MI355X (gfx950) kernels for the INR / SIREN
+ * super-resolution fit path of MRIRC/MRI-super-resolution.
+ *
+ * The reference has no FFI of its own: its boundary is the Python module surface of SRDWI.py /
+ * INRmodel.py / nn_mri.py, and all arithmetic is stock PyTorch ops.  Every entry point below
+ * therefore replaces a *framework op sequence* of the reference; the file:line of that sequence
+ * (relative to /root/reference/implicit-neural-representations) is cited per function.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, int64 sizes, scalar hyper-parameters, a hipStream_t passed as
+ *    void* (0 = the null stream).  No torch types, no ownership transfer: the caller allocates every
+ *    output and every workspace (size from the matching *_workspace_bytes query).
+ *  - every function only ENQUEUES work on `stream` and returns without synchronising (graph-capture
+ *    safe: no allocation, no host sync inside).
+ *  - return value: 0 = ok; negative = invalid argument (INR_E_*); positive = hipError_t.
+ *    inr_last_error() returns a thread-local human-readable message for the last failure.
+ *  - all tensors are dense row-major fp32.  Linear weights are [out_features][in_features] exactly as
+ *    torch.nn.Linear stores them.
+ *  - reductions (loss, bias/weight gradients) use fixed-order two-stage sums: no float atomics, so
+ *    two runs on the same inputs are bitwise identical.
+ */
+#ifndef INRHIP_H
+#define INRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INR_ABI_VERSION 1
+
+#define INR_E_INVALID   (-1)  /* null pointer / non-positive size / unsupported shape            */
+#define INR_E_WORKSPACE (-2)  /* workspace pointer null or smaller than the *_workspace_bytes query */
+#define INR_E_ALIGN     (-3)  /* pointer not 16-byte aligned where the kernel requires it         */
+
+typedef struct inr_device_caps {
+    int  abi_version;
+    int  device;
+    int  compute_units;
+    int  wavefront_size;
+    int  lds_bytes_per_cu;
+    int  clock_khz;
+    int64_t hbm_bytes;
+    char arch[32];          /* "gfx950..." */
+} inr_device_caps_t;
+
+/* Description of one SIREN: Siren(in, hidden, hidden_layers, out, first_omega_0, hidden_omega_0)
+ * (SRDWI.py:67-85).  Sine layers: 1 + hidden_layers; then the linear head. */
+typedef struct inr_siren_desc {
+    int   in_features;
+    int   hidden_features;
+    int   hidden_layers;
+    int   out_features;
+    float first_omega;
+    float hidden_omega;
+} inr_siren_desc_t;
+
+/* Flat parameter layout used by the fused entry points (network order):
+ *   W_0[hidden][in], b_0[hidden], W_1[hidden][hidden], b_1, ..., W_head[out][hidden], b_head[out]
+ * Every tensor starts at a multiple of 4 floats (16 B): offsets come from inr_siren_param_offsets. */
+
+int         inr_version(void);
+const char* inr_last_error(void);
+int         inr_device_caps(int device, inr_device_caps_t* out);
+
+/* ---- a-1: get_mgrid (SRDWI.py:12-18, nn_mri.py:87-94) ------------------------------------------
+ * rows [row_begin, row_begin+n_rows) of the flattened 'ij' meshgrid of linspace(-1,1,shape[a]),
+ * last axis fastest; bit-exact with torch.linspace (single-rounding fma rule).  dim<=8. */
+int inr_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, void* stream);
+
+/* ---- a-3: input_mapping (SRDWI.py:111-116) -----------------------------------------------------
+ * out[n][2m] = [sin(2*pi*x @ B^T) | cos(2*pi*x @ B^T)],  x[n][d], B[m][d]. */
+int inr_fourier_map(float* out, const float* x, const float* B, int64_t n, int d, int m, void* stream);
+/* Same, with x generated in-kernel from the grid (K1+K2 fused: the coordinate grid never reaches HBM;
+ * replaces get_mgrid(...).cuda() -> input_mapping at superresDWI.py:125-126). */
+int inr_grid_fourier_map(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
+                         const float* B, int m, void* stream);
+
+/* ---- a-4: SineLayer.forward (SRDWI.py:58-59): act = sin(omega*(x W^T + b)) ----------------------
+ * x[n][in], W[out][in], b[out] (nullable), act[n][out]; dact (nullable) receives
+ * omega*cos(omega*(x W^T + b)) -- the factor autograd multiplies by in backward. */
+int inr_sine_layer_forward(float* act, float* dact, const float* x, const float* W, const float* b,
+                           int64_t n, int in_features, int out_features, float omega, void* stream);
+
+/* element-wise out = a*b over `count` floats: dz = grad_out * dact, the first step of a stand-alone
+ * SineLayer's backward (what autograd does for torch.sin(omega*z), SRDWI.py:59).  out may alias a or b. */
+int inr_mul(float* out, const float* a, const float* b, int64_t count, void* stream);
+
+/* ---- a-5: final nn.Linear (SRDWI.py:75-77,83): y = a W^T + b, optional clamp(min) ---------------
+ * (clamp fuses torch.clamp(..., min=0) of superresDWI.py:161; pass use_clamp=0 for the raw head). */
+int inr_linear_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n,
+                            int in_features, int out_features, int use_clamp, float clamp_min, void* stream);
+
+/* ---- a-6: ((y-t)**2).mean() and its gradient (superresDWI.py:135; weighted: master.py:143-145) ---
+ * gy[i] = 2*w[i]*(y[i]-t[i])/count ; *loss = mean(w*(y-t)^2).  w nullable.  count = n*out. */
+size_t inr_mse_workspace_bytes(int64_t count);
+int inr_mse_loss_grad(float* gy, float* loss, const float* y, const float* t, const float* w,
+                      int64_t count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- a-6: backward pieces (what autograd runs for SRDWI.py:58-59,83) -----------------------------
+ * head:   dz_last[n][hidden] = (gy[n][out] @ W_head[out][hidden]) * dact_last   (in place over dact ok)
+ *         gW_head[out][hidden] = gy^T a_last ; gb_head[out] = colsum(gy) */
+size_t inr_head_backward_workspace_bytes(int64_t n, int hidden, int out_features);
+int inr_linear_head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
+                             const float* dact_last, const float* W, int64_t n, int hidden, int out_features,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* input grad through one sine layer: dz_prev[n][in] = (dz[n][out] @ W[out][in]) * dact_prev[n][in]
+ * (dz_prev may alias dact_prev).  With dact_prev == NULL writes the plain product dz @ W. */
+int inr_sine_layer_backward_input(float* dz_prev, const float* dz, const float* W, const float* dact_prev,
+                                  int64_t n, int in_features, int out_features, void* stream);
+/* parameter grads: gW[out][in] = dz^T x ; gb[out] = colsum(dz).  Split over rows + fixed-order reduce. */
+size_t inr_linear_param_grad_workspace_bytes(int64_t n, int in_features, int out_features);
+int inr_linear_param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n,
+                          int in_features, int out_features, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ---- a-7: torch.optim.Adam.step (superresDWI.py:116,138; defaults b=(0.9,0.999), eps=1e-8) ------
+ * One launch over `count` contiguous fp32 elements.  bias corrections are computed on the host in
+ * double exactly like torch's single-tensor path: step_size = lr/(1-b1^t), denom =
+ * sqrt(v)/sqrt(1-b2^t) + eps.  `step` is the 1-based step number. */
+int inr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, int64_t step,
+                  double lr, double beta1, double beta2, double eps, void* stream);
+
+/* ---- fused SIREN entry points (flat parameter buffer) ------------------------------------------ */
+int64_t inr_siren_param_count(const inr_siren_desc_t* desc);      /* padded flat length in floats */
+/* offsets[2*(hidden_layers+2)]: (W_l, b_l) float offsets in network order, head last */
+int  inr_siren_param_offsets(const inr_siren_desc_t* desc, int64_t* offsets);
+
+/* a-5 + a-9: y[n][out] = head(sine layers(x[n][in])), optional clamp; forward only, no stash. */
+size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n);
+int inr_siren_forward(const inr_siren_desc_t* desc, const float* params, const float* x, int64_t n,
+                      float* y, int use_clamp, float clamp_min, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* a-9: dense re-sampling clamp(INR(input_mapping(get_mgrid(shape), B)), min) -> y[prod(shape)][out]
+ * (superresDWI.py:125-126,161-162; superresHybrid.py:103-104,119).  Grid + Fourier features are
+ * generated chunk by chunk in the workspace (never the whole [N_test,2m] feature matrix).
+ * B == NULL means raw coordinates feed the network (nn_mri path, master.py:149-153). */
+size_t inr_siren_reconstruct_workspace_bytes(const inr_siren_desc_t* desc, int64_t chunk_rows);
+int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, const int64_t* shape, int dim,
+                          const float* B, int m, float* y, int use_clamp, float clamp_min,
+                          int64_t chunk_rows, void* workspace, size_t workspace_bytes, void* stream);
+
+/* a-8: `n_steps` full-batch fit steps (superresDWI.py:132-138; superresHybrid.py:109-114):
+ * forward with stash -> MSE (+optional weights) -> backward -> Adam, all enqueued on `stream`,
+ * no host sync.  params/grads/m/v are flat buffers of inr_siren_param_count floats.  losses[n_steps]
+ * (device, nullable) receives the loss of every step.  first_step is the 1-based Adam step of the
+ * first iteration (so a fit can be continued). */
+size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n);
+int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, float* m, float* v,
+                  const float* x, const float* target, const float* weight, int64_t n,
+                  int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps,
+                  float* losses, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
+ * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */
+int  inr_prof_enable(int enable);
+int  inr_prof_reset(void);
+/* synchronises the recorded events; returns launches and total milliseconds for a class */
+int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
+
+/* diagnostic: s[i] = sin(x[i]), c[i] = cos(x[i]) with the device routine used in the epilogues */
+int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INRHIP_H */

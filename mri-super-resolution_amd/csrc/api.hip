@@ -1,0 +1,508 @@
+// extern "C" surface of libinrhip.so (see include/inrhip.h) + the fused SIREN fit / forward /
+// reconstruct orchestration.  Nothing here allocates device memory or synchronises (except
+// inr_prof_read and inr_device_caps, which are not on the hot path).
+#include <math.h>
+#include <stdarg.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace inr {
+
+// ---- error string -------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiler -------------------------------------------------------------------------------------
+struct ProfState {
+    std::mutex mu;
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;                    // recycled events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[KC_COUNT];
+    hipEvent_t open[KC_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t get() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+static ProfState g_prof;
+bool prof_enabled() { return g_prof.enabled; }
+void prof_begin(int kc, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    hipEvent_t e = g_prof.get();
+    (void)hipEventRecord(e, s);
+    g_prof.open[kc] = e;
+}
+void prof_end(int kc, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    hipEvent_t e = g_prof.get();
+    (void)hipEventRecord(e, s);
+    g_prof.spans[kc].push_back({g_prof.open[kc], e});
+    g_prof.open[kc] = nullptr;
+}
+
+// ---- kernels implemented in gemm_f32.hip / kernels.hip ------------------------------------------------
+int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
+                      int in_f, int out_f, float omega, hipStream_t stream);
+int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
+                    int out_f, hipStream_t stream);
+int param_grad_splits(int64_t n, int in_f, int out_f);
+int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
+                          int out_f, hipStream_t stream);
+int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, hipStream_t st);
+int launch_fourier(float* out, const float* x, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
+                   const float* B, int m, hipStream_t st);
+int launch_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n, int hidden,
+                        int out_f, int use_clamp, float clamp_min, hipStream_t st);
+int mse_blocks(int64_t count);
+int launch_mse(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
+               float* partial, hipStream_t st);
+int launch_head_dz(float* dz, const float* gy, const float* W, const float* dact, int64_t n, int hidden,
+                   int out_f, hipStream_t st);
+int64_t colsum_chunks(int64_t n, int C);
+int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab,
+                  hipStream_t st);
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr, double b1,
+                double b2, double eps, hipStream_t st);
+int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
+int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st);
+
+// ---- shared helpers ---------------------------------------------------------------------------------
+static const int64_t MAX_ROWS = (1ll << 31) - 256;
+
+static int check_desc(const inr_siren_desc_t* d) {
+    INR_REQUIRE(d != nullptr, INR_E_INVALID, "siren descriptor is null");
+    INR_REQUIRE(d->in_features >= 1 && d->hidden_features >= 1 && d->hidden_layers >= 0 && d->out_features >= 1,
+                INR_E_INVALID, "bad siren descriptor (in=%d hidden=%d layers=%d out=%d)", d->in_features,
+                d->hidden_features, d->hidden_layers, d->out_features);
+    return 0;
+}
+
+struct Layout {
+    int n_sine;                      // 1 + hidden_layers
+    std::vector<int64_t> w_off, b_off;  // per layer, head last
+    std::vector<int> fan_in, fan_out;
+    int64_t total;
+};
+
+static Layout make_layout(const inr_siren_desc_t* d) {
+    Layout L;
+    L.n_sine = 1 + d->hidden_layers;
+    int64_t off = 0;
+    for (int l = 0; l <= L.n_sine; ++l) {
+        const int fin = (l == 0) ? d->in_features : d->hidden_features;
+        const int fout = (l == L.n_sine) ? d->out_features : d->hidden_features;
+        L.fan_in.push_back(fin);
+        L.fan_out.push_back(fout);
+        L.w_off.push_back(off);
+        off += (int64_t)round_up((size_t)fin * fout, 4);
+        L.b_off.push_back(off);
+        off += (int64_t)round_up((size_t)fout, 4);
+    }
+    L.total = off;
+    return L;
+}
+
+static size_t param_grad_ws_floats(int64_t n, int in_f, int out_f) {
+    const size_t slabs = (size_t)param_grad_splits(n, in_f, out_f) * (size_t)in_f * out_f;
+    const size_t col = (size_t)colsum_chunks(n, out_f) * (size_t)out_f;
+    return slabs > col ? slabs : col;
+}
+
+// gW = dz^T x, gb = colsum(dz); ws holds max(slabs, colsum chunks)
+static int param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n, int in_f, int out_f,
+                      float* ws, hipStream_t st) {
+    const int splits = param_grad_splits(n, in_f, out_f);
+    if (int rc = gemm_param_grad_slabs(ws, splits, dz, x, n, in_f, out_f, st)) return rc;
+    if (int rc = launch_reduce_slabs(gW, ws, splits, (int64_t)in_f * out_f, st)) return rc;
+    if (gb) {
+        if (int rc = launch_colsum(gb, dz, nullptr, n, out_f, 1, ws, st)) return rc;
+    }
+    return 0;
+}
+
+static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
+    const size_t a = (size_t)colsum_chunks(n, hidden) * (size_t)out_f * hidden;
+    const size_t b = (size_t)colsum_chunks(n, out_f) * (size_t)out_f;
+    return a > b ? a : b;
+}
+
+static int head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
+                         const float* dact_last, const float* W, int64_t n, int hidden, int out_f, float* ws,
+                         hipStream_t st) {
+    if (gW) {
+        if (int rc = launch_colsum(gW, a_last, gy, n, hidden, out_f, ws, st)) return rc;
+    }
+    if (gb) {
+        if (int rc = launch_colsum(gb, gy, nullptr, n, out_f, 1, ws, st)) return rc;
+    }
+    if (dz_last) return launch_head_dz(dz_last, gy, W, dact_last, n, hidden, out_f, st);
+    return 0;
+}
+
+}  // namespace inr
+
+using namespace inr;
+
+extern "C" {
+
+int inr_version(void) { return INR_ABI_VERSION; }
+const char* inr_last_error(void) { return g_err; }
+
+int inr_device_caps(int device, inr_device_caps_t* out) {
+    INR_REQUIRE(out != nullptr, INR_E_INVALID, "caps output is null");
+    hipDeviceProp_t prop;
+    INR_HIP(hipGetDeviceProperties(&prop, device));
+    memset(out, 0, sizeof(*out));
+    out->abi_version = INR_ABI_VERSION;
+    out->device = device;
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront_size = prop.warpSize;
+    out->lds_bytes_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_khz = prop.clockRate;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    return 0;
+}
+
+int inr_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, void* stream) {
+    INR_REQUIRE(out && shape, INR_E_INVALID, "inr_mgrid: null pointer");
+    INR_REQUIRE(row_begin >= 0 && n_rows >= 0, INR_E_INVALID, "inr_mgrid: negative row range");
+    return launch_mgrid(out, shape, dim, row_begin, n_rows, (hipStream_t)stream);
+}
+
+int inr_fourier_map(float* out, const float* x, const float* B, int64_t n, int d, int m, void* stream) {
+    INR_REQUIRE(out && x && B, INR_E_INVALID, "inr_fourier_map: null pointer");
+    INR_REQUIRE(n >= 0 && d >= 1 && m >= 1, INR_E_INVALID, "inr_fourier_map: bad sizes n=%lld d=%d m=%d",
+                (long long)n, d, m);
+    return launch_fourier(out, x, nullptr, d, 0, n, B, m, (hipStream_t)stream);
+}
+
+int inr_grid_fourier_map(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
+                         const float* B, int m, void* stream) {
+    INR_REQUIRE(out && shape && B, INR_E_INVALID, "inr_grid_fourier_map: null pointer");
+    INR_REQUIRE(row_begin >= 0 && n_rows >= 0 && m >= 1, INR_E_INVALID, "inr_grid_fourier_map: bad sizes");
+    return launch_fourier(out, nullptr, shape, dim, row_begin, n_rows, B, m, (hipStream_t)stream);
+}
+
+int inr_sine_layer_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
+                           int in_features, int out_features, float omega, void* stream) {
+    INR_REQUIRE(act && x && W, INR_E_INVALID, "inr_sine_layer_forward: null pointer");
+    INR_REQUIRE(n >= 0 && n <= MAX_ROWS && in_features >= 1 && out_features >= 1, INR_E_INVALID,
+                "inr_sine_layer_forward: bad sizes n=%lld in=%d out=%d", (long long)n, in_features, out_features);
+    if (n == 0) return 0;
+    return gemm_sine_forward(act, dact, x, W, b, n, in_features, out_features, omega, (hipStream_t)stream);
+}
+
+int inr_mul(float* out, const float* a, const float* b, int64_t count, void* stream) {
+    INR_REQUIRE(out && a && b && count >= 0, INR_E_INVALID, "inr_mul: bad arguments");
+    return launch_mul(out, a, b, count, (hipStream_t)stream);
+}
+
+int inr_linear_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n, int in_features,
+                            int out_features, int use_clamp, float clamp_min, void* stream) {
+    INR_REQUIRE(y && a && W, INR_E_INVALID, "inr_linear_head_forward: null pointer");
+    INR_REQUIRE(n >= 0 && in_features >= 1 && out_features >= 1, INR_E_INVALID, "inr_linear_head_forward: bad sizes");
+    return launch_head_forward(y, a, W, b, n, in_features, out_features, use_clamp, clamp_min, (hipStream_t)stream);
+}
+
+size_t inr_mse_workspace_bytes(int64_t count) { return (size_t)mse_blocks(count > 0 ? count : 1) * sizeof(float); }
+
+int inr_mse_loss_grad(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(gy && loss && y && t, INR_E_INVALID, "inr_mse_loss_grad: null pointer");
+    INR_REQUIRE(count >= 1, INR_E_INVALID, "inr_mse_loss_grad: count must be >= 1");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_mse_workspace_bytes(count), INR_E_WORKSPACE,
+                "inr_mse_loss_grad: workspace too small");
+    return launch_mse(gy, loss, y, t, w, count, (float*)workspace, (hipStream_t)stream);
+}
+
+size_t inr_head_backward_workspace_bytes(int64_t n, int hidden, int out_features) {
+    return head_backward_ws_floats(n > 0 ? n : 1, hidden, out_features) * sizeof(float);
+}
+
+int inr_linear_head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
+                             const float* dact_last, const float* W, int64_t n, int hidden, int out_features,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(gy && a_last && W, INR_E_INVALID, "inr_linear_head_backward: null pointer");
+    INR_REQUIRE(n >= 1 && hidden >= 1 && out_features >= 1, INR_E_INVALID, "inr_linear_head_backward: bad sizes");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_head_backward_workspace_bytes(n, hidden, out_features),
+                INR_E_WORKSPACE, "inr_linear_head_backward: workspace too small");
+    return head_backward(dz_last, gW, gb, gy, a_last, dact_last, W, n, hidden, out_features, (float*)workspace,
+                         (hipStream_t)stream);
+}
+
+int inr_sine_layer_backward_input(float* dz_prev, const float* dz, const float* W, const float* dact_prev, int64_t n,
+                                  int in_features, int out_features, void* stream) {
+    INR_REQUIRE(dz_prev && dz && W, INR_E_INVALID, "inr_sine_layer_backward_input: null pointer");
+    INR_REQUIRE(n >= 0 && n <= MAX_ROWS && in_features >= 1 && out_features >= 1, INR_E_INVALID,
+                "inr_sine_layer_backward_input: bad sizes");
+    if (n == 0) return 0;
+    return gemm_input_grad(dz_prev, dz, W, dact_prev, n, in_features, out_features, (hipStream_t)stream);
+}
+
+size_t inr_linear_param_grad_workspace_bytes(int64_t n, int in_features, int out_features) {
+    return param_grad_ws_floats(n > 0 ? n : 1, in_features, out_features) * sizeof(float);
+}
+
+int inr_linear_param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n, int in_features,
+                          int out_features, void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(gW && dz && x, INR_E_INVALID, "inr_linear_param_grad: null pointer");
+    INR_REQUIRE(n >= 1 && n <= MAX_ROWS && in_features >= 1 && out_features >= 1, INR_E_INVALID,
+                "inr_linear_param_grad: bad sizes");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_linear_param_grad_workspace_bytes(n, in_features, out_features),
+                INR_E_WORKSPACE, "inr_linear_param_grad: workspace too small");
+    return param_grad(gW, gb, dz, x, n, in_features, out_features, (float*)workspace, (hipStream_t)stream);
+}
+
+int inr_adam_step(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr,
+                  double beta1, double beta2, double eps, void* stream) {
+    INR_REQUIRE(p && g && m && v, INR_E_INVALID, "inr_adam_step: null pointer");
+    INR_REQUIRE(count >= 0 && step >= 1, INR_E_INVALID, "inr_adam_step: count >= 0 and step >= 1 required");
+    return launch_adam(p, g, m, v, count, step, lr, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+// ---- fused SIREN -------------------------------------------------------------------------------------
+int64_t inr_siren_param_count(const inr_siren_desc_t* desc) {
+    if (check_desc(desc)) return INR_E_INVALID;
+    return make_layout(desc).total;
+}
+
+int inr_siren_param_offsets(const inr_siren_desc_t* desc, int64_t* offsets) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(offsets != nullptr, INR_E_INVALID, "offsets is null");
+    const Layout L = make_layout(desc);
+    for (int l = 0; l <= L.n_sine; ++l) {
+        offsets[2 * l] = L.w_off[l];
+        offsets[2 * l + 1] = L.b_off[l];
+    }
+    return 0;
+}
+
+size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
+    if (check_desc(desc)) return 0;
+    return 2 * round_up((size_t)(n > 0 ? n : 1) * desc->hidden_features * sizeof(float), 256);
+}
+
+static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const float* params, const float* x,
+                              int64_t n, float* y, int use_clamp, float clamp_min, float* buf0, float* buf1,
+                              hipStream_t st) {
+    const float* cur = x;
+    float* bufs[2] = {buf0, buf1};
+    for (int l = 0; l < L.n_sine; ++l) {
+        float* dst = bufs[l & 1];
+        const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        if (int rc = gemm_sine_forward(dst, nullptr, cur, params + L.w_off[l], params + L.b_off[l], n, L.fan_in[l],
+                                       L.fan_out[l], omega, st))
+            return rc;
+        cur = dst;
+    }
+    return launch_head_forward(y, cur, params + L.w_off[L.n_sine], params + L.b_off[L.n_sine], n,
+                               d->hidden_features, d->out_features, use_clamp, clamp_min, st);
+}
+
+int inr_siren_forward(const inr_siren_desc_t* desc, const float* params, const float* x, int64_t n, float* y,
+                      int use_clamp, float clamp_min, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(params && x && y, INR_E_INVALID, "inr_siren_forward: null pointer");
+    INR_REQUIRE(n >= 0 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_forward: bad row count %lld", (long long)n);
+    if (n == 0) return 0;
+    INR_REQUIRE(workspace && workspace_bytes >= inr_siren_forward_workspace_bytes(desc, n), INR_E_WORKSPACE,
+                "inr_siren_forward: workspace too small");
+    INR_REQUIRE(aligned16(workspace), INR_E_ALIGN, "inr_siren_forward: workspace must be 16-byte aligned");
+    const Layout L = make_layout(desc);
+    const size_t half = round_up((size_t)n * desc->hidden_features * sizeof(float), 256);
+    float* b0 = (float*)workspace;
+    float* b1 = (float*)((char*)workspace + half);
+    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream);
+}
+
+size_t inr_siren_reconstruct_workspace_bytes(const inr_siren_desc_t* desc, int64_t chunk_rows) {
+    if (check_desc(desc) || chunk_rows < 1) return 0;
+    const size_t feats = round_up((size_t)chunk_rows * desc->in_features * sizeof(float), 256);
+    const size_t act = round_up((size_t)chunk_rows * desc->hidden_features * sizeof(float), 256);
+    return feats + 2 * act;
+}
+
+int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, const int64_t* shape, int dim,
+                          const float* B, int m, float* y, int use_clamp, float clamp_min, int64_t chunk_rows,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(params && shape && y, INR_E_INVALID, "inr_siren_reconstruct: null pointer");
+    INR_REQUIRE(dim >= 1 && dim <= 8, INR_E_INVALID, "inr_siren_reconstruct: dim must be 1..8");
+    INR_REQUIRE(chunk_rows >= 1 && chunk_rows <= MAX_ROWS, INR_E_INVALID, "inr_siren_reconstruct: bad chunk_rows");
+    if (B)
+        INR_REQUIRE(2 * m == desc->in_features, INR_E_INVALID,
+                    "inr_siren_reconstruct: in_features (%d) must equal 2*m (%d)", desc->in_features, 2 * m);
+    else
+        INR_REQUIRE(dim == desc->in_features, INR_E_INVALID,
+                    "inr_siren_reconstruct: without B the grid dim (%d) must equal in_features (%d)", dim,
+                    desc->in_features);
+    INR_REQUIRE(workspace && workspace_bytes >= inr_siren_reconstruct_workspace_bytes(desc, chunk_rows),
+                INR_E_WORKSPACE, "inr_siren_reconstruct: workspace too small");
+    INR_REQUIRE(aligned16(workspace), INR_E_ALIGN, "inr_siren_reconstruct: workspace must be 16-byte aligned");
+    int64_t total = 1;
+    for (int a = 0; a < dim; ++a) {
+        INR_REQUIRE(shape[a] >= 1, INR_E_INVALID, "inr_siren_reconstruct: shape[%d] must be >= 1", a);
+        total *= shape[a];
+    }
+    const Layout L = make_layout(desc);
+    const size_t feats_b = round_up((size_t)chunk_rows * desc->in_features * sizeof(float), 256);
+    const size_t act_b = round_up((size_t)chunk_rows * desc->hidden_features * sizeof(float), 256);
+    float* feats = (float*)workspace;
+    float* b0 = (float*)((char*)workspace + feats_b);
+    float* b1 = (float*)((char*)workspace + feats_b + act_b);
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t r0 = 0; r0 < total; r0 += chunk_rows) {
+        const int64_t rows = (total - r0 < chunk_rows) ? (total - r0) : chunk_rows;
+        int rc = B ? launch_fourier(feats, nullptr, shape, dim, r0, rows, B, m, st)
+                   : launch_mgrid(feats, shape, dim, r0, rows, st);
+        if (rc) return rc;
+        rc = siren_forward_impl(desc, L, params, feats, rows, y + r0 * desc->out_features, use_clamp, clamp_min, b0,
+                                b1, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// workspace carve for the fit: acts (n_sine x n x H), dacts (n_sine x n x H), y, gy, scratch
+struct FitCarve {
+    size_t act_b, out_b, scratch_b, total;
+};
+static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n) {
+    FitCarve c;
+    c.act_b = round_up((size_t)n * d->hidden_features * sizeof(float), 256);
+    c.out_b = round_up((size_t)n * d->out_features * sizeof(float), 256);
+    size_t scratch = head_backward_ws_floats(n, d->hidden_features, d->out_features);
+    for (int l = 0; l < L.n_sine; ++l) {
+        const size_t s = param_grad_ws_floats(n, L.fan_in[l], L.fan_out[l]);
+        if (s > scratch) scratch = s;
+    }
+    const size_t mse = (size_t)mse_blocks((int64_t)n * d->out_features) + 1;
+    if (mse > scratch) scratch = mse;
+    c.scratch_b = round_up(scratch * sizeof(float), 256);
+    c.total = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
+    return c;
+}
+
+size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
+    if (check_desc(desc) || n < 1) return 0;
+    const Layout L = make_layout(desc);
+    return fit_carve(desc, L, n).total;
+}
+
+int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, float* m, float* v, const float* x,
+                  const float* target, const float* weight, int64_t n, int64_t first_step, int n_steps, double lr,
+                  double beta1, double beta2, double eps, float* losses, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(params && grads && m && v && x && target, INR_E_INVALID, "inr_siren_fit: null pointer");
+    INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_fit: bad row count %lld", (long long)n);
+    INR_REQUIRE(first_step >= 1 && n_steps >= 0, INR_E_INVALID, "inr_siren_fit: first_step >= 1, n_steps >= 0");
+    const Layout L = make_layout(desc);
+    const FitCarve c = fit_carve(desc, L, n);
+    INR_REQUIRE(workspace && workspace_bytes >= c.total, INR_E_WORKSPACE,
+                "inr_siren_fit: workspace too small (%zu < %zu)", workspace_bytes, c.total);
+    INR_REQUIRE(aligned16(workspace) && aligned16(params) && aligned16(grads) && aligned16(x), INR_E_ALIGN,
+                "inr_siren_fit: params/grads/x/workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)workspace;
+    std::vector<float*> act(L.n_sine + 1), dact(L.n_sine);
+    act[0] = const_cast<float*>(x);
+    for (int l = 0; l < L.n_sine; ++l) {
+        act[l + 1] = (float*)(base + (size_t)l * c.act_b);
+        dact[l] = (float*)(base + (size_t)(L.n_sine + l) * c.act_b);
+    }
+    float* y = (float*)(base + 2 * (size_t)L.n_sine * c.act_b);
+    float* gy = (float*)((char*)y + c.out_b);
+    float* scratch = (float*)((char*)gy + c.out_b);
+    float* loss_sink = scratch;  // overwritten later in the step; only used when losses == nullptr
+    const int H = desc->hidden_features, O = desc->out_features, head = L.n_sine;
+
+    for (int it = 0; it < n_steps; ++it) {
+        // forward with stash (SRDWI.py:58-59 per layer; dact = omega*cos(.) replaces autograd's saved z)
+        for (int l = 0; l < L.n_sine; ++l) {
+            const float omega = (l == 0) ? desc->first_omega : desc->hidden_omega;
+            if (int rc = gemm_sine_forward(act[l + 1], dact[l], act[l], params + L.w_off[l], params + L.b_off[l], n,
+                                           L.fan_in[l], L.fan_out[l], omega, st))
+                return rc;
+        }
+        if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
+                                         0.f, st))
+            return rc;
+        // loss + dL/dy (superresDWI.py:135)
+        float* loss_dst = losses ? (losses + it) : loss_sink;
+        if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st)) return rc;
+        // backward: head, then sine layers from last to first; dz overwrites dact in place
+        if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head], gy, act[head],
+                                   dact[head - 1], params + L.w_off[head], n, H, O, scratch, st))
+            return rc;
+        for (int l = L.n_sine - 1; l >= 0; --l) {
+            if (int rc = param_grad(grads + L.w_off[l], grads + L.b_off[l], dact[l], act[l], n, L.fan_in[l],
+                                    L.fan_out[l], scratch, st))
+                return rc;
+            if (l > 0) {
+                if (int rc = gemm_input_grad(dact[l - 1], dact[l], params + L.w_off[l], dact[l - 1], n, L.fan_in[l],
+                                             L.fan_out[l], st))
+                    return rc;
+            }
+        }
+        if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
+    }
+    return 0;
+}
+
+// ---- profiler --------------------------------------------------------------------------------------------
+int inr_prof_enable(int enable) {
+    g_prof.enabled = enable != 0;
+    return 0;
+}
+
+int inr_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (int k = 0; k < KC_COUNT; ++k) {
+        for (auto& sp : g_prof.spans[k]) {
+            g_prof.pool.push_back(sp.first);
+            g_prof.pool.push_back(sp.second);
+        }
+        g_prof.spans[k].clear();
+    }
+    return 0;
+}
+
+int inr_prof_read(int kernel_class, int64_t* launches, double* total_ms) {
+    INR_REQUIRE(kernel_class >= 0 && kernel_class < KC_COUNT && launches && total_ms, INR_E_INVALID,
+                "inr_prof_read: bad arguments");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double ms = 0.0;
+    for (auto& sp : g_prof.spans[kernel_class]) {
+        INR_HIP(hipEventSynchronize(sp.second));
+        float t = 0.f;
+        INR_HIP(hipEventElapsedTime(&t, sp.first, sp.second));
+        ms += t;
+    }
+    *launches = (int64_t)g_prof.spans[kernel_class].size();
+    *total_ms = ms;
+    return 0;
+}
+
+int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream) {
+    INR_REQUIRE(s && c && x && n >= 0, INR_E_INVALID, "inr_sincos_probe: bad arguments");
+    return launch_sincos_probe(s, c, x, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

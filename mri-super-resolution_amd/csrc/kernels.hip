@@ -1,0 +1,398 @@
+// Bandwidth-bound kernels of the INR fit path: coordinate grid, Fourier features, linear head
+// (wavefront-shuffle row reduction), MSE residual/gradient, head backward, fixed-order column sums
+// and slab reductions (bias / weight gradients, loss), fused Adam.  All fp32, no float atomics.
+#include "common.h"
+
+namespace inr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GridShape {
+    int64_t n[8];
+    int dim;
+};
+
+// ---- a-1: get_mgrid (SRDWI.py:12-18) ---------------------------------------------------------------
+__global__ void mgrid_kernel(float* __restrict__ out, GridShape g, int64_t row_begin, int64_t n_rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    int64_t rem = row_begin + i;
+    float v[8];
+#pragma unroll
+    for (int a = 7; a >= 0; --a) {
+        if (a < g.dim) {
+            const int64_t idx = rem % g.n[a];
+            rem /= g.n[a];
+            v[a] = linspace_pm1(idx, g.n[a]);
+        }
+    }
+    float* o = out + i * g.dim;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+        if (a < g.dim) o[a] = v[a];
+}
+
+// ---- a-3: input_mapping (SRDWI.py:111-116); FROM_GRID fuses get_mgrid in -----------------------------
+// one thread per (row, frequency j): proj = sum_a fl(2*pi*x_a) * B[j][a]; out[row][j] = sin, [m+j] = cos
+template <bool FROM_GRID>
+__global__ void fourier_kernel(float* __restrict__ out, const float* __restrict__ x, GridShape g, int d,
+                               int64_t row_begin, int64_t n_rows, const float* __restrict__ B, int m) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * m) return;
+    const int64_t row = t / m;
+    const int j = (int)(t - row * m);
+    const float two_pi = 6.283185307179586f;
+    float proj = 0.f;
+    if (FROM_GRID) {
+        int64_t rem = row_begin + row;
+        float c[8];
+#pragma unroll
+        for (int a = 7; a >= 0; --a) {
+            if (a < g.dim) {
+                const int64_t idx = rem % g.n[a];
+                rem /= g.n[a];
+                c[a] = linspace_pm1(idx, g.n[a]);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+            if (a < g.dim) proj = fmaf(two_pi * c[a], B[j * g.dim + a], proj);
+    } else {
+        for (int a = 0; a < d; ++a) proj = fmaf(two_pi * x[row * d + a], B[j * d + a], proj);
+    }
+    float s, c;
+    sincos_f32(proj, s, c);
+    out[row * (2 * m) + j] = s;
+    out[row * (2 * m) + m + j] = c;
+}
+
+// ---- a-5: head y = a W^T + b; one wave per row, shuffle reduction ---------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) head_forward_kernel(float* __restrict__ y, const float* __restrict__ a,
+                                                           const float* __restrict__ W,
+                                                           const float* __restrict__ b, int64_t n, int hidden,
+                                                           int out_f, int use_clamp, float clamp_min) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave0; row < n; row += nwaves) {
+        const float* ar = a + row * hidden;
+        for (int o = 0; o < out_f; ++o) {
+            const float* w = W + (int64_t)o * hidden;
+            float acc = 0.f;
+            if (VEC) {
+                for (int k = lane * 4; k < hidden; k += 256) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ar + k);
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + k);
+                    acc = fmaf(av[0], wv[0], acc);
+                    acc = fmaf(av[1], wv[1], acc);
+                    acc = fmaf(av[2], wv[2], acc);
+                    acc = fmaf(av[3], wv[3], acc);
+                }
+            } else {
+                for (int k = lane; k < hidden; k += 64) acc = fmaf(ar[k], w[k], acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                float v = acc + (b ? b[o] : 0.f);
+                if (use_clamp) v = fmaxf(v, clamp_min);
+                y[row * out_f + o] = v;
+            }
+        }
+    }
+}
+
+// ---- a-6: residual, gradient, per-block loss partials ------------------------------------------------
+__global__ void __launch_bounds__(256) mse_kernel(float* __restrict__ gy, float* __restrict__ partial,
+                                                  const float* __restrict__ y, const float* __restrict__ t,
+                                                  const float* __restrict__ w, int64_t count, float inv_count) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float r = y[i] - t[i];
+        const float wr = w ? w[i] * r : r;
+        gy[i] = 2.0f * wr * inv_count;
+        acc = fmaf(wr, r, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// final fixed-order sum of `nparts` partials, scaled
+__global__ void __launch_bounds__(256) finish_sum_kernel(float* __restrict__ out, const float* __restrict__ partial,
+                                                         int nparts, float scale) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+// ---- head backward: dz_last[row][k] = (sum_o gy[row][o] W[o][k]) * dact[row][k] --------------------
+__global__ void __launch_bounds__(256) head_dz_kernel(float* __restrict__ dz, const float* __restrict__ gy,
+                                                      const float* __restrict__ W,
+                                                      const float* __restrict__ dact, int64_t n, int hidden,
+                                                      int out_f) {
+    const int64_t total = n * hidden;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t row = i / hidden;
+        const int k = (int)(i - row * hidden);
+        float da = 0.f;
+        for (int o = 0; o < out_f; ++o) da = fmaf(gy[row * out_f + o], W[(int64_t)o * hidden + k], da);
+        dz[i] = dact ? da * dact[i] : da;
+    }
+}
+
+// ---- weighted column sums over a row chunk ----------------------------------------------------------
+// slab[chunk][gi][c] = sum_{row in chunk} g[row][gi] * X[row][c]   (g == nullptr: G = 1, weight 1)
+// grid = (chunks, ceil(C/256)); thread = one column; rows streamed, coalesced across the block.
+__global__ void __launch_bounds__(256) colsum_kernel(float* __restrict__ slab, const float* __restrict__ X,
+                                                     const float* __restrict__ g, int64_t n, int C, int G,
+                                                     int64_t rows_per_chunk) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r1 = min(n, r0 + rows_per_chunk);
+    for (int gi = 0; gi < G; ++gi) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int64_t r = r0;
+        if (g) {
+            for (; r + 3 < r1; r += 4) {
+                a0 = fmaf(g[(r + 0) * G + gi], X[(r + 0) * C + c], a0);
+                a1 = fmaf(g[(r + 1) * G + gi], X[(r + 1) * C + c], a1);
+                a2 = fmaf(g[(r + 2) * G + gi], X[(r + 2) * C + c], a2);
+                a3 = fmaf(g[(r + 3) * G + gi], X[(r + 3) * C + c], a3);
+            }
+            for (; r < r1; ++r) a0 = fmaf(g[r * G + gi], X[r * C + c], a0);
+        } else {
+            for (; r + 3 < r1; r += 4) {
+                a0 += X[(r + 0) * C + c];
+                a1 += X[(r + 1) * C + c];
+                a2 += X[(r + 2) * C + c];
+                a3 += X[(r + 3) * C + c];
+            }
+            for (; r < r1; ++r) a0 += X[r * C + c];
+        }
+        slab[((int64_t)blockIdx.x * G + gi) * C + c] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// out[i] = sum_{s < nslabs} slab[s][i]  (fixed order)
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slab,
+                                                           int nslabs, int64_t len) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    float a0 = 0.f, a1 = 0.f;
+    int s = 0;
+    for (; s + 1 < nslabs; s += 2) {
+        a0 += slab[(int64_t)s * len + i];
+        a1 += slab[(int64_t)(s + 1) * len + i];
+    }
+    if (s < nslabs) a0 += slab[(int64_t)s * len + i];
+    out[i] = a0 + a1;
+}
+
+// ---- a-7: Adam (torch single-tensor formulation) ---------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t count,
+                                                   float one_minus_b1, float b2, float one_minus_b2,
+                                                   float step_size, float bc2_sqrt, float eps) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float gi = g[i];
+        const float mi = fmaf(gi - m[i], one_minus_b1, m[i]);           // m.lerp_(g, 1-b1)
+        const float vi = fmaf(one_minus_b2 * gi, gi, v[i] * b2);        // v*b2 + (1-b2)*g*g
+        const float denom = __fsqrt_rn(vi) / bc2_sqrt + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+__global__ void __launch_bounds__(256) mul_kernel(float* out, const float* a, const float* b, int64_t count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = a[i] * b[i];
+}
+
+__global__ void sincos_probe_kernel(float* s, float* c, const float* x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_f32(x[i], s[i], c[i]);
+}
+
+// ================================= host launchers ====================================================
+static inline unsigned blocks_for(int64_t work, int per_block, int64_t cap) {
+    int64_t b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+static int fill_shape(GridShape& g, const int64_t* shape, int dim) {
+    INR_REQUIRE(shape && dim >= 1 && dim <= 8, INR_E_INVALID, "grid dim must be 1..8 (got %d)", dim);
+    g.dim = dim;
+    for (int a = 0; a < 8; ++a) g.n[a] = 1;
+    for (int a = 0; a < dim; ++a) {
+        INR_REQUIRE(shape[a] >= 1, INR_E_INVALID, "grid shape[%d] = %lld must be >= 1", a, (long long)shape[a]);
+        g.n[a] = shape[a];
+    }
+    return 0;
+}
+
+int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, hipStream_t st) {
+    GridShape g;
+    if (int rc = fill_shape(g, shape, dim)) return rc;
+    if (n_rows == 0) return 0;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(mgrid_kernel, dim3(blocks_for(n_rows, 256, 1 << 30)), dim3(256), 0, st, out, g, row_begin,
+                       n_rows);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_fourier(float* out, const float* x, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
+                   const float* B, int m, hipStream_t st) {
+    GridShape g;
+    g.dim = dim;
+    for (int a = 0; a < 8; ++a) g.n[a] = 1;
+    if (!x) {
+        if (int rc = fill_shape(g, shape, dim)) return rc;
+    }
+    if (n_rows == 0) return 0;
+    const int64_t work = n_rows * m;
+    ProfScope ps(KC_OTHER, st);
+    if (x)
+        hipLaunchKernelGGL(fourier_kernel<false>, dim3(blocks_for(work, 256, 1ll << 31)), dim3(256), 0, st, out, x,
+                           g, dim, row_begin, n_rows, B, m);
+    else
+        hipLaunchKernelGGL(fourier_kernel<true>, dim3(blocks_for(work, 256, 1ll << 31)), dim3(256), 0, st, out, x, g,
+                           dim, row_begin, n_rows, B, m);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n, int hidden,
+                        int out_f, int use_clamp, float clamp_min, hipStream_t st) {
+    if (n == 0) return 0;
+    const bool vec = aligned16(a) && aligned16(W) && (hidden % 4 == 0);
+    ProfScope ps(KC_OTHER, st);
+    const dim3 grid(blocks_for(n, 4, 256 * 32));
+    if (vec)
+        hipLaunchKernelGGL(head_forward_kernel<true>, grid, dim3(256), 0, st, y, a, W, b, n, hidden, out_f,
+                           use_clamp, clamp_min);
+    else
+        hipLaunchKernelGGL(head_forward_kernel<false>, grid, dim3(256), 0, st, y, a, W, b, n, hidden, out_f,
+                           use_clamp, clamp_min);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int mse_blocks(int64_t count) { return (int)blocks_for(count, 256 * 4, 2048); }
+
+int launch_mse(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
+               float* partial, hipStream_t st) {
+    const int nb = mse_blocks(count);
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, gy, partial, y, t, w, count,
+                       (float)(1.0 / (double)count));
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, loss, partial, nb,
+                       (float)(1.0 / (double)count));
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_head_dz(float* dz, const float* gy, const float* W, const float* dact, int64_t n, int hidden,
+                   int out_f, hipStream_t st) {
+    if (n == 0) return 0;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(head_dz_kernel, dim3(blocks_for(n * hidden, 256, 256 * 64)), dim3(256), 0, st, dz, gy, W,
+                       dact, n, hidden, out_f);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// chunking used by the column-sum path: ~2048 blocks, at least 32 rows per chunk
+int64_t colsum_rows_per_chunk(int64_t n, int C) {
+    const int64_t col_groups = (C + 255) / 256;
+    int64_t chunks = 2048 / col_groups;
+    if (chunks < 1) chunks = 1;
+    int64_t rpc = (n + chunks - 1) / chunks;
+    if (rpc < 32) rpc = 32;
+    return rpc;
+}
+int64_t colsum_chunks(int64_t n, int C) {
+    const int64_t rpc = colsum_rows_per_chunk(n, C);
+    return (n + rpc - 1) / rpc;
+}
+
+// out[G][C] = sum_rows g[row][gi]*X[row][c]; slab must hold colsum_chunks(n,C)*G*C floats
+int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab,
+                  hipStream_t st) {
+    const int64_t rpc = colsum_rows_per_chunk(n, C);
+    const int64_t chunks = (n + rpc - 1) / rpc;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)chunks, (unsigned)((C + 255) / 256)), dim3(256), 0, st, slab, X,
+                       g, n, C, G, rpc);
+    INR_LAUNCH_CHECK();
+    const int64_t len = (int64_t)G * C;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(len, 256, 1 << 30)), dim3(256), 0, st, out, slab,
+                       (int)chunks, len);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, hipStream_t st) {
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(len, 256, 1 << 30)), dim3(256), 0, st, out, slab, nslabs,
+                       len);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr, double b1,
+                double b2, double eps, hipStream_t st) {
+    if (count == 0) return 0;
+    // host-side double bias corrections, as torch's _single_tensor_adam does for python-float lr
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    const double step_size = lr / bc1;
+    const double bc2_sqrt = sqrt(bc2);
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(count, 256, 4096)), dim3(256), 0, st, p, g, m, v, count,
+                       (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)step_size, (float)bc2_sqrt,
+                       (float)eps);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st) {
+    if (count == 0) return 0;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks_for(count, 256, 256 * 32)), dim3(256), 0, st, out, a, b, count);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sincos_probe_kernel, dim3(blocks_for(n, 256, 1 << 30)), dim3(256), 0, st, s, c, x, n);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace inr

@@ -29,7 +29,10 @@ def sha(a):
 
 
 def strided(a, k=97):
-    return np.ascontiguousarray(a.reshape(-1)[::k])
+    """Every k-th element as an owning COPY (a 1-element slice would otherwise alias live parameter memory);
+    tensors of <= 512 elements are kept whole."""
+    flat = a.reshape(-1)
+    return np.array(flat if flat.size <= 512 else flat[::k], copy=True)
 
 
 def save(name, **kw):

@@ -24,3 +24,9 @@ def golden():
         return cache[name]
 
     return load
+
+
+def strided_sample(a, k=97):
+    """The sampling rule of oracle/gen_golden.py: tensors of <= 512 elements whole, else every k-th element."""
+    flat = np.asarray(a).reshape(-1)
+    return flat if flat.size <= 512 else flat[::k]

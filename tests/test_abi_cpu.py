@@ -1,0 +1,132 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/inrhip.h declares, the ctypes table covers them all, host-side construction matches the
+reference bit for bit, and the product path refuses to run without a HIP device."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import mri_super_resolution_amd as inr
+from mri_super_resolution_amd import _lib
+from mri_super_resolution_amd._build import LIB_PATH, build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "inrhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(inr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    build_library()
+    assert os.path.exists(LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in inrhip.h but not exported"
+    assert sorted(_lib.SIGNATURES.keys()) == syms
+    assert _lib.lib().inr_version() == 1
+
+
+def test_host_only_entry_points_without_gpu():
+    lib = _lib.lib()
+    desc = _lib.SirenDesc(256, 512, 3, 1, 30.0, 30.0)
+    total = lib.inr_siren_param_count(ctypes.byref(desc))
+    assert total == 256 * 512 + 512 + 3 * (512 * 512 + 512) + 512 + 4
+    offs = (ctypes.c_int64 * 10)()
+    assert lib.inr_siren_param_offsets(ctypes.byref(desc), offs) == 0
+    assert list(offs)[:4] == [0, 131072, 131584, 131584 + 262144]
+    assert all(o % 4 == 0 for o in offs)
+    assert lib.inr_siren_fit_workspace_bytes(ctypes.byref(desc), 4096) > 8 * 4096 * 512 * 4
+    bad = _lib.SirenDesc(0, 512, 3, 1, 30.0, 30.0)
+    assert lib.inr_siren_param_count(ctypes.byref(bad)) == -1
+    assert b"bad siren descriptor" in lib.inr_last_error()
+    # argument validation happens before any device work
+    assert lib.inr_mgrid(None, None, 2, 0, 4, None) == -1
+    assert lib.inr_adam_step(None, None, None, None, 4, 1, 1e-4, 0.9, 0.999, 1e-8, None) == -1
+
+
+@pytest.mark.parametrize("flavor", ["SRDWI", "INRmodel"])
+def test_siren_init_is_bit_identical_to_reference(golden, flavor):
+    g = golden("siren512_step0.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1, flavor=flavor)
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [k.split("/", 2)[2] for k in g.files if k.startswith(f"{flavor}/init_sha/")]
+    for n, p in net.named_parameters():
+        assert sha(p.detach().numpy()) == str(g[f"{flavor}/init_sha/{n}"]), n
+    keys = list(net.state_dict().keys())
+    assert "net.4.weight" in keys and "final_linear.bias" in keys and "net.0.linear.weight" in keys
+
+
+def test_small_siren_init_and_state_dict_roundtrip(golden):
+    s = golden("siren64_2d.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1)
+    for n, p in net.named_parameters():
+        assert np.array_equal(p.detach().numpy(), s[f"init/{n}"]), n
+    m = golden("model_pt.npz")
+    sd = {k.replace("__", "."): torch.from_numpy(m[k]) for k in m.files if k.startswith("net__")}
+    net2 = inr.Siren(2, 64, 3, 1)
+    missing, unexpected = net2.load_state_dict(sd, strict=False)
+    assert unexpected == [] and set(missing) == {"final_linear.weight", "final_linear.bias"}
+    assert torch.equal(net2.final_linear.weight, sd["net.4.weight"])  # alias of the shared head
+
+
+def test_no_cpu_fallback():
+    torch.manual_seed(0)
+    net = inr.Siren(2, 16, 1, 1)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the refusal path is exercised on the CPU runner")
+    with pytest.raises(inr.InrDeviceError):
+        net(torch.zeros(4, 2))
+    with pytest.raises(inr.InrDeviceError):
+        inr.get_mgrid((4, 4))
+    with pytest.raises(inr.InrDeviceError):
+        inr.ImageFitting_set([np.zeros((4, 4))])
+    with pytest.raises(inr.InrDeviceError):
+        inr.SirenFitter(net)
+    with pytest.raises(inr.InrDeviceError):
+        inr.input_mapping(torch.zeros(4, 2), torch.zeros(8, 2))
+
+
+def test_host_helpers(golden):
+    h = golden("helpers.npz")
+    assert np.allclose(inr.calculate_ADC(h["bvals"], h["slicedata"]), h["adc"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(inr.resize_array(h["resize_in"], 9), h["resize_out"], rtol=1e-12, atol=1e-12)
+    raw = [[np.full((2, 2, 2), 0.5)] * 2] + [[np.arange(2 * 2 * 2 * 3, dtype=float).reshape(2, 2, 2, 3) + b] * 2
+                                             for b in (1, 2, 3)]
+    combos = inr.calculate_combinations((1, 0, 1), raw)
+    assert combos.shape == (4, 27)
+    assert combos[0].tolist() == [0.5] * 27
+
+
+def test_compat_modules_import():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "mri-super-resolution_amd", "compat"))
+    try:
+        import INRmodel
+        import SRDWI
+        import nn_mri
+    finally:
+        sys.path.pop(0)
+    for name in ("calculate_combinations", "ImageFitting_set", "Siren", "PN", "get_mgrid", "input_mapping",
+                 "calculate_ADC", "resize_array"):
+        assert hasattr(SRDWI, name) and hasattr(INRmodel, name)
+    for name in ("ImageFitting_set", "Siren", "get_mgrid", "SineLayer", "PN", "input_mapping"):
+        assert hasattr(nn_mri, name)
+    torch.manual_seed(0)
+    a = INRmodel.Siren(8, 16, 1, 1)
+    assert a.flavor == "INRmodel" and list(dict(a.named_parameters()))[0] == "final_linear.weight"
+    assert nn_mri.Siren(2, 8, 1, 1).return_coords is True

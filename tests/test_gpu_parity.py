@@ -1,0 +1,411 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures
+generated from the reference.  Tolerances follow the tiers of SURVEY.md 7.3:
+  T0 grids bit-exact; T1 forward <= 1e-5 rel-L2; T2 loss/gradients <= 1e-5; T3 K<=50-step trajectories <= 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import mri_super_resolution_amd as inr
+from mri_super_resolution_amd import ops
+from oracle import inr_oracle as O
+from oracle import torch_port as P
+from conftest import strided_sample
+
+pytestmark = pytest.mark.gpu
+
+T1 = 1e-5
+T2 = 1e-5
+T3 = 1e-4
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need a HIP device"
+    caps = ops.device_caps(0)
+    assert caps["arch"].startswith("gfx950"), caps
+    assert caps["wavefront_size"] == 64
+    yield
+
+
+# ------------------------------------------------------------------ T0: grids ------------------------------
+@pytest.mark.parametrize("shape", [(64, 64), (5, 7, 3), (25, 25, 21, 4), (1, 4), (128, 128, 28), (3,), (2, 3, 2, 2, 3)])
+def test_mgrid_bit_exact(shape):
+    got = host(inr.get_mgrid(shape))
+    assert np.array_equal(bits(got), bits(O.mgrid(shape)))
+
+
+def test_mgrid_golden_and_2d_form(golden):
+    g = golden("grids.npz")
+    assert np.array_equal(bits(host(inr.get_mgrid((5, 7, 3)))), bits(g["full_5x7x3"]))
+    assert np.array_equal(bits(host(inr.get_mgrid((64, 64)))[:8]), bits(g["head_64x64"]))
+    assert np.array_equal(bits(host(inr.get_mgrid(60, 2))), bits(O.mgrid_square(60, 2)))
+    for key in g.files:
+        if key.startswith("lin_"):
+            n = int(key[4:])
+            assert np.array_equal(bits(host(inr.get_mgrid((n,)))[:, 0]), bits(g[key])), n
+
+
+def test_mgrid_row_ranges_and_large_axis():
+    full = O.mgrid((9, 11, 5))
+    part = host(ops.mgrid((9, 11, 5), row_begin=123, n_rows=200))
+    assert np.array_equal(bits(part), bits(full[123:323]))
+    assert host(ops.mgrid((4, 4), row_begin=16, n_rows=0)).shape == (0, 2)
+    big = host(inr.get_mgrid((100001,)))[:, 0]
+    assert np.array_equal(bits(big), bits(O.linspace_pm1(100001)))
+    with pytest.raises(ValueError):
+        ops.mgrid((4, 4), row_begin=10, n_rows=10)
+
+
+# ------------------------------------------------------------------ datasets + Fourier features ------------
+def test_image_fitting_set(golden):
+    g = golden("dataset_ff.npz")
+    lr = golden("pat07_slice11.npz")["lr"]
+    ds = inr.ImageFitting_set([lr.astype(np.float64)])
+    assert ds.shape == (64, 64) and len(ds) == 1
+    assert np.array_equal(bits(host(ds.pixels)), bits(g["lr_pixels"]))
+    img3 = g["img3"]
+    ds3 = inr.ImageFitting_set([img3, img3 * 2])
+    assert np.array_equal(bits(host(ds3.pixels)), bits(g["ds3_pixels"]))
+    assert np.array_equal(bits(host(ds3.coords)), bits(g["ds3_coords"]))
+    c, p = ds3[0]
+    assert c is ds3.coords and p is ds3.pixels
+
+
+def test_fourier_features(golden):
+    g = golden("dataset_ff.npz")
+    ff2 = host(inr.input_mapping(inr.get_mgrid((64, 64)), dev(g["B2"])))
+    assert O.rel_l2(ff2[::17], g["ff2_rows"]) < 2e-6
+    ff3 = host(inr.input_mapping(inr.get_mgrid((5, 7, 3)), dev(g["B3"])))
+    assert O.rel_l2(ff3, g["ff3"]) < 2e-6
+    ff4 = host(inr.input_mapping(inr.get_mgrid((3, 4, 2, 4)), dev(g["B4"])))
+    assert O.rel_l2(ff4, g["ff4"]) < 2e-6
+    fused = host(ops.grid_fourier_map((3, 4, 2, 4), dev(g["B4"])))
+    assert np.array_equal(bits(fused), bits(ff4))            # grid-fused == two-step, bit for bit
+    part = host(ops.grid_fourier_map((5, 7, 3), dev(g["B3"]), row_begin=17, n_rows=40))
+    assert np.array_equal(bits(part), bits(ff3[17:57]))
+    x = inr.get_mgrid((3, 3))
+    assert inr.input_mapping(x, None) is x
+
+
+def test_sincos_accuracy():
+    rng = np.random.default_rng(0)
+    for scale in (1.0, 8.0, 64.0, 1000.0, 6.0e4, 3.0e6):
+        x = ((rng.random(200000) * 2 - 1) * scale).astype(np.float32)
+        s, c = ops.sincos_probe(dev(x))
+        xs = x.astype(np.float64)
+        assert np.abs(host(s) - np.sin(xs)).max() < 2.5e-7, scale
+        assert np.abs(host(c) - np.cos(xs)).max() < 2.5e-7, scale
+    s, c = ops.sincos_probe(dev(np.array([0.0, -0.0, np.pi / 2, -np.pi, 1e-30], np.float32)))
+    assert np.allclose(host(s), [0, 0, 1, 8.742278e-08, 1e-30], atol=1e-7)
+
+
+# ------------------------------------------------------------------ T1: forward -------------------------------
+def _siren512(golden, flavor="SRDWI"):
+    d = golden("dataset_ff.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1, flavor=flavor)
+    net.cuda()
+    x = inr.input_mapping(inr.get_mgrid((64, 64)), dev(d["B2"]))
+    return net, x, d
+
+
+@pytest.mark.parametrize("flavor", ["SRDWI", "INRmodel"])
+def test_forward_matches_reference(golden, flavor):
+    g = golden("siren512_step0.npz")
+    net, x, _ = _siren512(golden, flavor)
+    with torch.no_grad():
+        y = host(net(x))
+    assert y.shape == (4096, 1)
+    assert O.rel_l2(y, g[f"{flavor}/fwd"]) < T1
+    desc, flat = inr.flat_parameters(net)
+    y2 = host(ops.siren_forward(desc, flat, x))
+    assert np.array_equal(bits(y2), bits(y))                 # fused entry point == per-layer path
+
+
+def test_forward_model_pt_checkpoint(golden):
+    m = golden("model_pt.npz")
+    net = inr.Siren(2, 64, 3, 1)
+    net.load_state_dict({k.replace("__", "."): torch.from_numpy(m[k]) for k in m.files if k.startswith("net__")},
+                        strict=False)
+    net.cuda()
+    with torch.no_grad():
+        y = host(net(inr.get_mgrid(128, 2))).reshape(128, 128)
+    assert O.rel_l2(y, m["fwd128"]) < T1
+    rec = host(inr.reconstruct(net, (128, 128), None, clamp_min=None))
+    assert O.rel_l2(rec, m["fwd128"]) < T1
+    rec0 = host(inr.reconstruct(net, (128, 128), None, clamp_min=0.0))
+    assert np.array_equal(rec0, np.maximum(rec, 0.0))
+
+
+@pytest.mark.parametrize("n,fin,hidden,layers,out", [(1, 2, 64, 1, 1), (129, 3, 40, 2, 2), (1000, 256, 128, 0, 1),
+                                                      (257, 7, 130, 1, 3)])
+def test_forward_ragged_shapes_vs_oracle(n, fin, hidden, layers, out):
+    """Edge shapes: single row, sizes that are not tile multiples, unaligned feature counts (scalar-load
+    path), no hidden layers, several outputs."""
+    torch.manual_seed(n)
+    ref = P.PortSiren(fin, hidden, layers, out)
+    torch.manual_seed(n)
+    net = inr.Siren(fin, hidden, layers, out).cuda()
+    x = torch.rand(n, fin) * 2 - 1
+    ws, bs = ref.layer_params()
+    want = O.siren_forward(ws, bs, x.numpy().astype(np.float64), dtype=np.float64)
+    with torch.no_grad():
+        got = host(net(x.cuda()))
+    assert got.shape == (n, out)
+    assert O.rel_l2(got, want) < T1
+
+
+# ------------------------------------------------------------------ T2: loss + gradients ------------------------
+def test_gradients_match_reference(golden):
+    g = golden("siren512_step0.npz")
+    net, x, d = _siren512(golden)
+    t = dev(d["lr_pixels"][0])
+    out = net(x)
+    loss = ((out - t) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - g["SRDWI/loss0"]) / g["SRDWI/loss0"] < T2
+    for n, p in net.named_parameters():
+        gr = host(p.grad)
+        assert O.rel_l2(strided_sample(gr), g[f"SRDWI/grad_strided/{n}"]) < T2, n
+        nrm = np.linalg.norm(gr.astype(np.float64))
+        assert abs(nrm - g[f"SRDWI/grad_norm/{n}"]) / g[f"SRDWI/grad_norm/{n}"] < T2, n
+        if f"SRDWI/grad_full/{n}" in g.files:
+            assert O.rel_l2(gr, g[f"SRDWI/grad_full/{n}"]) < T2, n
+    # full tensors against the live torch port (same ops as the reference)
+    torch.manual_seed(0)
+    ref = P.PortSiren(256, 512, 3, 1)
+    xr = torch.from_numpy(host(x))
+    ((ref(xr) - torch.from_numpy(d["lr_pixels"][0])) ** 2).mean().backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert O.rel_l2(host(p.grad), q.grad.numpy()) < T2, n
+
+
+def test_fused_loss_grad_kernels_vs_oracle(golden):
+    """inr_mse_loss_grad + fused fit gradients == autograd path gradients (same kernels, bit for bit)."""
+    net, x, d = _siren512(golden)
+    t = dev(d["lr_pixels"][0])
+    w = dev((np.random.default_rng(1).random((4096, 1)) > 0.3).astype(np.float32))
+    with torch.no_grad():
+        y = net(x)
+    for weight in (None, w):
+        loss, gy = ops.mse_loss_grad(y, t, weight)
+        want_loss, want_g = O.mse_loss_and_grad(host(y), host(t), None if weight is None else host(weight),
+                                                dtype=np.float64)
+        assert abs(loss.item() - want_loss) / want_loss < 1e-6
+        assert O.rel_l2(host(gy), want_g) < 1e-6
+    out = net(x)
+    ((out - t) ** 2).mean().backward()
+    auto = {n: host(p.grad).copy() for n, p in net.named_parameters()}
+    fitter = inr.SirenFitter(net, lr=0.0)                       # lr = 0: parameters stay put
+    losses = fitter.step(x, t, n_steps=1)
+    names = ["net.%d.linear.%s" % (l, k) for l in range(4) for k in ("weight", "bias")] + \
+            ["final_linear.weight", "final_linear.bias"]
+    for l, (w_off, b_off) in enumerate(fitter.offsets):
+        gw = host(fitter.grads[w_off:w_off + auto[names[2 * l]].size]).reshape(auto[names[2 * l]].shape)
+        gb = host(fitter.grads[b_off:b_off + auto[names[2 * l + 1]].size])
+        # the fit path feeds gy from the fused MSE kernel, autograd from torch's mean/pow backward: equal to rounding
+        assert O.rel_l2(gw, auto[names[2 * l]]) < 2e-6, names[2 * l]
+        assert O.rel_l2(gb, auto[names[2 * l + 1]]) < 2e-6, names[2 * l + 1]
+    assert abs(losses[0].item() - golden("siren512_step0.npz")["SRDWI/loss0"]) < 1e-5 * losses[0].item()
+
+
+def test_small_2d_weighted_gradients(golden):
+    s = golden("siren64_2d.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1).cuda()
+    x, t, w = dev(s["coords"]), dev(s["target"]), dev(s["weight"])
+    y = net(x)
+    assert O.rel_l2(host(y), s["fwd"]) < T1
+    loss = (w * (y - t) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - s["loss0"]) / s["loss0"] < T2
+    for n, p in net.named_parameters():
+        assert O.rel_l2(host(p.grad), s[f"grad/{n}"]) < 2 * T2, n
+
+
+def test_input_gradient_inrmodel_flavor():
+    """INRmodel.Siren does not detach coords (INRmodel.py:147): gradient must reach the input."""
+    torch.manual_seed(3)
+    ref = P.PortSiren(6, 48, 2, 1, flavor="INRmodel")
+    torch.manual_seed(3)
+    net = inr.Siren(6, 48, 2, 1, flavor="INRmodel").cuda()
+    x0 = torch.rand(200, 6) * 2 - 1
+    xr = x0.clone().requires_grad_(True)
+    ref(xr).pow(2).sum().backward()
+    xg = x0.clone().cuda().requires_grad_(True)
+    net(xg).pow(2).sum().backward()
+    assert O.rel_l2(host(xg.grad), xr.grad.numpy()) < T2
+    xs = x0.clone().cuda().requires_grad_(True)
+    torch.manual_seed(3)
+    net_s = inr.Siren(6, 48, 2, 1, flavor="SRDWI").cuda()
+    net_s(xs).sum().backward()
+    assert xs.grad is None                                      # SRDWI.py:88 detaches
+
+
+def test_standalone_sine_layer_autograd():
+    torch.manual_seed(5)
+    lay = inr.SineLayer(12, 20, is_first=True, omega_0=30)
+    ref_w, ref_b = lay.linear.weight.detach().clone(), lay.linear.bias.detach().clone()
+    lay.cuda()
+    x0 = torch.rand(77, 12) * 2 - 1
+    xg = x0.clone().cuda().requires_grad_(True)
+    out = lay(xg)
+    out.square().sum().backward()
+    xr = x0.clone().double().requires_grad_(True)
+    wr, br = ref_w.double().requires_grad_(True), ref_b.double().requires_grad_(True)
+    o = torch.sin(30 * (xr @ wr.T + br))
+    o.square().sum().backward()
+    assert O.rel_l2(host(out), o.detach().numpy()) < T1
+    assert O.rel_l2(host(xg.grad), xr.grad.numpy()) < T2
+    assert O.rel_l2(host(lay.linear.weight.grad), wr.grad.numpy()) < T2
+    assert O.rel_l2(host(lay.linear.bias.grad), br.grad.numpy()) < T2
+
+
+# ------------------------------------------------------------------ Adam ------------------------------------------
+def test_adam_kernel_vs_oracle_and_torch():
+    rng = np.random.default_rng(2)
+    n = 10007
+    p0 = rng.standard_normal(n).astype(np.float32)
+    p, m, v = dev(p0), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    pn, mn, vn = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pt = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=3e-4)
+    for step in range(1, 8):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 1)).astype(np.float32)
+        ops.adam_step(p, dev(g), m, v, step, 3e-4)
+        O.adam_step(pn, g, mn, vn, step, 3e-4)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        assert np.allclose(host(p), pn, rtol=3e-6, atol=1e-9), step
+        assert np.allclose(host(p), pt.detach().numpy(), rtol=3e-6, atol=1e-9), step
+    assert np.allclose(host(m), mn, rtol=1e-5, atol=1e-6 * np.abs(mn).max())   # m cancels: absolute floor
+    assert np.allclose(host(v), vn, rtol=1e-5, atol=1e-20)
+
+
+# ------------------------------------------------------------------ T3: short trajectories ------------------------
+def test_trajectory_50_steps_fused_vs_reference(golden):
+    tr = golden("siren512_traj.npz")
+    net, x, d = _siren512(golden)
+    t = dev(d["lr_pixels"][0])
+    B = dev(d["B2"])
+    fitter = inr.SirenFitter(net, lr=1e-4)
+    losses = []
+    done = 0
+    for upto in (1, 10, 50):
+        losses.append(host(fitter.step(x, t, n_steps=upto - done)))
+        done = upto
+        rec = host(inr.reconstruct(net, (128, 128), B))
+        assert O.rel_l2(rec, tr[f"t8/recon_{upto}"]) < T3, upto
+        for n, p in net.named_parameters():
+            a = host(p)
+            sample = strided_sample(a, 997)
+            assert O.rel_l2(sample, tr[f"t8/pstrided_{upto}/{n}"]) < T3, (upto, n)
+            nrm = np.linalg.norm(a.astype(np.float64))
+            assert abs(nrm - tr[f"t8/pnorm_{upto}/{n}"]) / tr[f"t8/pnorm_{upto}/{n}"] < T3, (upto, n)
+    losses = np.concatenate(losses)
+    assert np.allclose(losses, tr["t8/losses"], rtol=2e-4)
+    assert fitter.step_count == 50
+
+
+def test_trajectory_autograd_path_external_adam(golden):
+    """The compatibility mode: reference-style loop with torch.optim.Adam + loss.backward()."""
+    tr = golden("siren512_traj.npz")
+    net, x, d = _siren512(golden)
+    t = dev(d["lr_pixels"][0])
+    opt = torch.optim.Adam(lr=1e-4, params=list(net.parameters()))
+    for _ in range(10):
+        out = net.forward(x)
+        loss = ((out - t) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    rec = host(inr.reconstruct(net, (128, 128), dev(d["B2"])))
+    assert O.rel_l2(rec, tr["t8/recon_10"]) < T3
+
+
+def test_trajectory_small_2d_weighted(golden):
+    s = golden("siren64_2d.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1).cuda()
+    x, t, w = dev(s["coords"]), dev(s["target"]), dev(s["weight"])
+    fitter = inr.SirenFitter(net, lr=3e-4)
+    losses = host(fitter.step(x, t, n_steps=10, weight=w))
+    assert np.allclose(losses, s["losses"][:10], rtol=2e-4)
+    for n, p in net.named_parameters():
+        assert O.rel_l2(host(p), s[f"p10/{n}"]) < T3, n
+    rec = host(inr.reconstruct(net, (180, 180), None, clamp_min=None))
+    assert O.rel_l2(rec, s["recon180_10"]) < T3
+
+
+def test_fit_is_bitwise_deterministic(golden):
+    res = []
+    for _ in range(2):
+        net, x, d = _siren512(golden)
+        fitter = inr.SirenFitter(net, lr=1e-4)
+        fitter.step(x, dev(d["lr_pixels"][0]), n_steps=5)
+        res.append(host(fitter.flat).copy())
+    assert np.array_equal(bits(res[0]), bits(res[1]))
+
+
+# ------------------------------------------------------------------ dense re-sampling --------------------------------
+@pytest.mark.parametrize("shape,dimB", [((33, 17), 2), ((9, 10, 7), 3), ((5, 6, 3, 4), 4)])
+def test_reconstruct_vs_oracle_and_chunk_invariance(shape, dimB):
+    torch.manual_seed(1)
+    ref = P.PortSiren(64, 96, 2, 1)
+    torch.manual_seed(1)
+    net = inr.Siren(64, 96, 2, 1).cuda()
+    B = P.fourier_matrix(dimB, mapping_size=32, seed=4)
+    ws, bs = ref.layer_params()
+    want = O.reconstruct(ws, bs, shape, B.astype(np.float64), dtype=np.float64)
+    got = host(inr.reconstruct(net, shape, torch.from_numpy(B)))
+    assert got.shape == tuple(shape)
+    assert O.rel_l2(got, want) < T1
+    small = host(inr.reconstruct(net, shape, torch.from_numpy(B), chunk_rows=37))
+    assert np.array_equal(bits(small), bits(got))               # tiling never changes a voxel's value
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE configs) ----------
+def test_full_size_synthetic128_properties():
+    """Synthetic 128^3 (LR 64x64x128, N = 524,288): properties that need no CPU reference at this size:
+    chunk invariance of the forward, additivity of parameter gradients over row blocks, and the fused
+    step equal to the sum of its parts."""
+    n_lr = 64 * 64 * 128
+    B = dev(P.fourier_matrix(3))
+    x = ops.grid_fourier_map((64, 64, 128), B)
+    assert x.shape == (n_lr, 256)
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1).cuda()
+    desc, flat = inr.flat_parameters(net)
+    y_full = ops.siren_forward(desc, flat, x)
+    lo, hi = 100000, 100000 + 4099
+    y_part = ops.siren_forward(desc, flat, x[lo:hi].contiguous())
+    assert torch.equal(y_full[lo:hi], y_part)
+    # oracle on a bounded sample of rows
+    rows = np.random.default_rng(0).choice(n_lr, 256, replace=False)
+    ws = [host(p) for p in net.layer_parameters()[0::2]]
+    bs = [host(p) for p in net.layer_parameters()[1::2]]
+    want = O.siren_forward(ws, bs, host(x[torch.from_numpy(rows).cuda()]).astype(np.float64), dtype=np.float64)
+    assert O.rel_l2(host(y_full)[rows], want) < T1
+    # additivity of dW over row blocks
+    dz = torch.randn(n_lr, 512, device="cuda") * 1e-3
+    gW, gb = ops.linear_param_grad(dz, x)
+    h = n_lr // 2 + 1000
+    gW1, gb1 = ops.linear_param_grad(dz[:h].contiguous(), x[:h].contiguous())
+    gW2, gb2 = ops.linear_param_grad(dz[h:].contiguous(), x[h:].contiguous())
+    assert O.rel_l2(host(gW1 + gW2), host(gW)) < 1e-5
+    assert O.rel_l2(host(gb1 + gb2), host(gb)) < 1e-5
+    ref_gb = dz.double().sum(0)
+    assert O.rel_l2(host(gb), host(ref_gb)) < 1e-5

@@ -8,6 +8,7 @@ import torch
 
 from oracle import inr_oracle as O
 from oracle import torch_port as P
+from conftest import strided_sample
 
 
 def sha(a):
@@ -127,14 +128,14 @@ def test_loss_and_gradients(golden):
         byname[f"net.{l}.linear.bias"] = gb[l]
     for n in PARAM_ORDER_SRDWI:
         ref_s = g[f"SRDWI/grad_strided/{n}"]
-        assert O.rel_l2(byname[n].reshape(-1)[::97], ref_s) < 1e-5, n
+        assert O.rel_l2(strided_sample(byname[n]), ref_s) < 1e-5, n
         nrm = np.linalg.norm(byname[n])
         assert abs(nrm - g[f"SRDWI/grad_norm/{n}"]) / g[f"SRDWI/grad_norm/{n}"] < 1e-5, n
     # torch port autograd: same ops as the reference
     out = net(torch.from_numpy(x))
     ((out - torch.from_numpy(t)) ** 2).mean().backward()
     for n, p in net.named_parameters():
-        assert O.rel_l2(p.grad.numpy().reshape(-1)[::97], g[f"SRDWI/grad_strided/{n}"]) < 1e-5, n
+        assert O.rel_l2(strided_sample(p.grad.numpy()), g[f"SRDWI/grad_strided/{n}"]) < 1e-5, n
 
 
 def test_short_trajectory_port_and_numpy_adam(golden):
