@@ -163,6 +163,9 @@ int  inr_prof_reset(void);
 /* synchronises the recorded events; returns launches and total milliseconds for a class */
 int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
 
+/* tuning/debug switches (not for production use): key 0 = force the generic GEMM kernel (0/1) */
+int inr_debug_set(int key, int value);
+
 /* diagnostic: s[i] = sin(x[i]), c[i] = cos(x[i]) with the device routine used in the epilogues */
 int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream);
 

@@ -4,22 +4,32 @@
 //   input-grad (K6)                 dz_prev = (dz W) * dact_prev                  A k-contig, B n-contig
 //   param-grad (K6)                 gW = dz^T x  (split over rows, slabs)         A m-contig, B n-contig
 //
-// One kernel template: 128x128x32 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a
-// 64x64 sub-tile as 2x2 v_mfma_f32_32x32x2_f32 accumulators (exact fp32 products, fp32 accumulate --
-// the only MFMA form on gfx950 that meets the 1e-5 parity tier; peak 157.3 TFLOP/s).
-// Operand tiles are staged global -> registers -> LDS (double-buffered, one barrier per K-step).
+// 128x128x32 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 sub-tile as 2x2
+// v_mfma_f32_32x32x2_f32 accumulators (exact fp32 products, fp32 accumulate -- the only MFMA form on
+// gfx950 that meets the 1e-5 parity tier; peak 157.3 TFLOP/s).
 // LDS images: k-contiguous operands as [rows][BK+4] (row stride 9 x 16 B: ds_read_b128 of 16 rows
 // hits 16 distinct 16-B slots), m/n-contiguous operands as [BK][128] read with ds_read_b32.
 // Within an 8-wide k block lane-half h consumes k = 4h..4h+3 for BOTH operands (a fixed permutation
 // of the k-sum, so one b128 read feeds four MFMAs).
 // blockIdx is remapped so that consecutive logical tiles (which share an A row-panel) land on the
 // same XCD and reuse it from that XCD's L2.
+//
+// Two kernels share the tile layout and the epilogue:
+//   gemm_f32_pipe_kernel  -- the hot one.  Operands come through buffer loads (per-block SRD: rows past
+//       the matrix end read as 0, no exec-mask branches), fragments are prefetched one 8-wide k block
+//       ahead into a second register set, the next tile's global loads / LDS stores are interleaved
+//       between the MFMAs with sched_group_barrier, and the single barrier per K-step sits between the
+//       third and fourth k block so the MFMAs that follow it already have their operands in registers.
+//       (Two co-resident blocks of a CU run in lockstep; whatever a wave does outside its MFMA stream
+//       leaves the matrix pipe idle for both, so that part is squeezed to the barrier itself.)
+//   gemm_f32_kernel       -- generic fallback (any shape/alignment: scalar guarded loads), same numerics.
 #include "common.h"
 
 namespace inr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
 constexpr int LDK = BK + 4;  // k-contiguous LDS row stride (floats)
@@ -41,11 +51,132 @@ struct GemmParams {
     int splits;
     long long slab_stride;  // floats between consecutive split slabs of C
     int tiles_m, tiles_n;
+    long long a_elems, b_elems, c_elems;  // total element counts of A, B, C (SRD bounds of the fast path)
 };
 
-// ---- tile movers ---------------------------------------------------------------------------------
+template <bool KC>
+struct TileSize {
+    static constexpr int floats = KC ? BM * LDK : BK * LDM;
+};
+
+// bijective XCD-aware remap: physical block id -> logical id such that logical ids that are close
+// together run on the same XCD (blocks are dealt round-robin over the 8 XCDs).
+__device__ __forceinline__ int xcd_remap(int pid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = pid & 7, idx = pid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+struct TileCoord {
+    int tile_m, tile_n, split;
+};
+__device__ __forceinline__ TileCoord decode_block(const GemmParams& p) {
+    const int total = p.tiles_m * p.tiles_n * p.splits;
+    int logical = xcd_remap(blockIdx.x, total);
+    TileCoord c;
+    c.tile_n = logical % p.tiles_n;
+    logical /= p.tiles_n;
+    c.tile_m = logical % p.tiles_m;
+    c.split = logical / p.tiles_m;
+    return c;
+}
+
+// ---- LDS tile movers (shared by both kernels) --------------------------------------------------------
 // k-contiguous operand: element (r, k) at P[r*ld + k]; LDS [r][k] stride LDK.
 // r-contiguous operand: element (r, k) at P[k*ld + r]; LDS [k][r] stride LDM.
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, const f32x4 (&reg)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KCONTIG) {
+            const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
+            *reinterpret_cast<f32x4*>(S + r * LDK + k) = reg[i];
+        } else {
+            const int k = (tid >> 5) + 8 * i, r = (tid & 31) * 4;
+            *reinterpret_cast<f32x4*>(S + k * LDM + r) = reg[i];
+        }
+    }
+}
+
+// fragment of 4 k-values (k = kb*8 + 4h + 0..3) for row `r` of the tile
+template <bool KCONTIG>
+__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int r, int kb, int h) {
+    if (KCONTIG) {
+        return *reinterpret_cast<const f32x4*>(S + r * LDK + kb * 8 + 4 * h);
+    } else {
+        const float* p = S + (kb * 8 + 4 * h) * LDM + r;
+        f32x4 v;
+        v[0] = p[0];
+        v[1] = p[LDM];
+        v[2] = p[2 * LDM];
+        v[3] = p[3 * LDM];
+        return v;
+    }
+}
+
+struct Frags {
+    f32x4 a[2], b[2];
+};
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void read_frags(Frags& f, const float* __restrict__ sA, const float* __restrict__ sB,
+                                           int arow, int brow, int kb, int h) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f.a[i] = read_frag<A_KC>(sA, arow + i * 32, kb, h);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.b[j] = read_frag<B_KC>(sB, brow + j * 32, kb, h);
+}
+
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[2][2], const Frags& f) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+}
+
+// ---- epilogue (C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)) ----
+template <int EPI, bool CHECK>
+__device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm,
+                                         int wn, int h, int l32, int split) {
+    float* __restrict__ C = p.C + (long long)split * p.slab_stride;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        if (CHECK && col >= p.N) continue;
+        float bias = 0.f;
+        if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row_base = m0 + wm * 64 + i * 32 + 4 * h;
+            const long long base = (long long)row_base * p.ldc + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (CHECK && row_base + dr >= p.M) continue;
+                const long long off = base + (long long)dr * p.ldc;
+                const float v = acc[i][j][r];
+                if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
+                    float s, c;
+                    sincos_f32(p.omega * (v + bias), s, c);
+                    C[off] = s;
+                    if (EPI == EPI_SINE_STASH) p.C2[off] = p.omega * c;
+                } else if (EPI == EPI_MUL) {
+                    C[off] = v * p.mul[off];
+                } else {
+                    C[off] = v;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// generic kernel: guarded (optionally scalar) global loads, plain double-buffered loop
+// =====================================================================================================
 template <bool KCONTIG, bool VEC>
 __device__ __forceinline__ void load_tile(f32x4 (&reg)[4], const float* __restrict__ P, int ld, int r0, int k0,
                                           int r_end, int k_end, int tid) {
@@ -78,50 +209,6 @@ __device__ __forceinline__ void load_tile(f32x4 (&reg)[4], const float* __restri
     }
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, const f32x4 (&reg)[4], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (KCONTIG) {
-            const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
-            *reinterpret_cast<f32x4*>(S + r * LDK + k) = reg[i];
-        } else {
-            const int k = (tid >> 5) + 8 * i, r = (tid & 31) * 4;
-            *reinterpret_cast<f32x4*>(S + k * LDM + r) = reg[i];
-        }
-    }
-}
-
-// fragment of 4 k-values (k = kb*8 + 4h + 0..3) for row `r` of the tile
-template <bool KCONTIG>
-__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int r, int kb, int h) {
-    if (KCONTIG) {
-        return *reinterpret_cast<const f32x4*>(S + r * LDK + kb * 8 + 4 * h);
-    } else {
-        const float* p = S + (kb * 8 + 4 * h) * LDM + r;
-        f32x4 v;
-        v[0] = p[0];
-        v[1] = p[LDM];
-        v[2] = p[2 * LDM];
-        v[3] = p[3 * LDM];
-        return v;
-    }
-}
-
-template <bool KC>
-struct TileSize {
-    static constexpr int floats = KC ? BM * LDK : BK * LDM;
-};
-
-// bijective XCD-aware remap: physical block id -> logical id such that logical ids that are close
-// together run on the same XCD (blocks are dealt round-robin over the 8 XCDs).
-__device__ __forceinline__ int xcd_remap(int pid, int total) {
-    const int q = total >> 3, r = total & 7;
-    const int xcd = pid & 7, idx = pid >> 3;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
-
 template <bool A_KC, bool B_KC, int EPI, bool VEC>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (TileSize<A_KC>::floats + TileSize<B_KC>::floats)];
@@ -132,16 +219,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(const GemmParams 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, l32 = lane & 31;
-
-    const int total = p.tiles_m * p.tiles_n * p.splits;
-    int logical = xcd_remap(blockIdx.x, total);
-    const int tile_n = logical % p.tiles_n;
-    logical /= p.tiles_n;
-    const int tile_m = logical % p.tiles_m;
-    const int split = logical / p.tiles_m;
-
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int k_begin = split * p.k_per_split;
+    const TileCoord tc = decode_block(p);
+    const int m0 = tc.tile_m * BM, n0 = tc.tile_n * BN;
+    const int k_begin = tc.split * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int ktiles = (k_end - k_begin + BK - 1) / BK;
 
@@ -174,18 +254,9 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(const GemmParams 
         const float* cB = cA + BOFF;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            f32x4 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<A_KC>(cA, wm * 64 + i * 32 + l32, kb, h);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<B_KC>(cB, wn * 64 + j * 32 + l32, kb, h);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            Frags f;
+            read_frags<A_KC, B_KC>(f, cA, cB, wm * 64 + l32, wn * 64 + l32, kb, h);
+            mfma_block(acc, f);
         }
         if (more) {
             store_tile<A_KC>(smem + (cur ^ 1) * STAGE, ra, tid);
@@ -193,37 +264,163 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(const GemmParams 
         }
         __syncthreads();
     }
+    epilogue<EPI, true>(p, acc, m0, n0, wm, wn, h, l32, tc.split);
+}
 
-    // ---- epilogue: C/D map of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)
-    float* __restrict__ C = p.C + (long long)split * p.slab_stride;
+// =====================================================================================================
+// pipelined kernel (fast path)
+// =====================================================================================================
+// per-block buffer resource over [base, base + bytes): loads past the end return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* base, long long bytes) {
+    if (bytes < 0) bytes = 0;
+    if (bytes > 0xFFFFFFFFll) bytes = 0xFFFFFFFFll;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(unsigned)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t srd, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, voff, soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+// byte offsets (relative to the block's SRD base) of this thread's 4 float4 of a tile at k-tile 0
+template <bool KCONTIG>
+__device__ __forceinline__ void tile_voffsets(int (&voff)[4], int ld, int tid) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l32;
-        if (col >= p.N) continue;
-        float bias = 0.f;
-        if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) bias = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                const long long off = (long long)row * p.ldc + col;
-                const float v = acc[i][j][r];
-                if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
-                    float s, c;
-                    sincos_f32(p.omega * (v + bias), s, c);
-                    C[off] = s;
-                    if (EPI == EPI_SINE_STASH) p.C2[off] = p.omega * c;
-                } else if (EPI == EPI_MUL) {
-                    C[off] = v * p.mul[off];
-                } else {
-                    C[off] = v;
-                }
-            }
-        }
+    for (int i = 0; i < 4; ++i) {
+        if (KCONTIG)
+            voff[i] = (((tid >> 3) + 32 * i) * ld + (tid & 7) * 4) * 4;
+        else
+            voff[i] = (((tid >> 5) + 8 * i) * ld + (tid & 31) * 4) * 4;
     }
 }
+
+// scheduling recipe for one 8-wide k block: 16 MFMAs with NR LDS fragment reads and NX extra memory
+// instructions (mask XMASK: 0x20 = VMEM read, 0x200 = DS write) spread evenly between them
+template <int NR, int NX, int XMASK, int I>
+__device__ __forceinline__ void sched_interleave() {
+    if constexpr (I < 16) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int r = (I + 1) * NR / 16 - I * NR / 16;
+        if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);
+        constexpr int x = (I + 1) * NX / 16 - I * NX / 16;
+        if constexpr (x > 0) __builtin_amdgcn_sched_group_barrier(XMASK, x, 0);
+        sched_interleave<NR, NX, XMASK, I + 1>();
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TileSize<A_KC>::floats + TileSize<B_KC>::floats)];
+    constexpr int STAGE = TileSize<A_KC>::floats + TileSize<B_KC>::floats;
+    constexpr int BOFF = TileSize<A_KC>::floats;
+    constexpr int NR = (A_KC ? 2 : 8) + (B_KC ? 2 : 8);  // LDS read instructions per k block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l32 = lane & 31;
+    const TileCoord tc = decode_block(p);
+    const int m0 = tc.tile_m * BM, n0 = tc.tile_n * BN;
+    const int k_begin = tc.split * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int ktiles = (k_end - k_begin + BK - 1) / BK;
+
+    // block-local SRDs: base at the tile's first element, extent to the end of the operand
+    const long long a_first = A_KC ? ((long long)m0 * p.lda + k_begin) : ((long long)k_begin * p.lda + m0);
+    const long long b_first = B_KC ? ((long long)n0 * p.ldb + k_begin) : ((long long)k_begin * p.ldb + n0);
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A + a_first, (p.a_elems - a_first) * 4);
+    const __amdgpu_buffer_rsrc_t srdB = make_srd(p.B + b_first, (p.b_elems - b_first) * 4);
+    const int a_step = (A_KC ? BK : BK * p.lda) * 4;  // bytes per K-tile
+    const int b_step = (B_KC ? BK : BK * p.ldb) * 4;
+    int va[4], vb[4];
+    tile_voffsets<A_KC>(va, p.lda, tid);
+    tile_voffsets<B_KC>(vb, p.ldb, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    f32x4 ra[4], rb[4];
+    Frags f0, f1;
+
+    if (ktiles > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = buf_load4(srdA, va[i], 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = buf_load4(srdB, vb[i], 0);
+        store_tile<A_KC>(smem, ra, tid);
+        store_tile<B_KC>(smem + BOFF, rb, tid);
+    }
+    __syncthreads();
+    if (ktiles > 0) read_frags<A_KC, B_KC>(f0, smem, smem + BOFF, arow, brow, 0, h);
+
+    int a_off = 0, b_off = 0;
+    for (int t = 0; t + 1 < ktiles; ++t) {
+        const float* cA = smem + (t & 1) * STAGE;
+        const float* cB = cA + BOFF;
+        float* nA = smem + ((t & 1) ^ 1) * STAGE;
+        float* nB = nA + BOFF;
+        a_off += a_step;
+        b_off += b_step;
+        // k block 0: MFMAs on f0; prefetch fragments of k block 1; issue the next tile's global loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = buf_load4(srdA, va[i], a_off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = buf_load4(srdB, vb[i], b_off);
+        read_frags<A_KC, B_KC>(f1, cA, cB, arow, brow, 1, h);
+        mfma_block(acc, f0);
+        sched_interleave<NR, 8, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        // k block 1
+        read_frags<A_KC, B_KC>(f0, cA, cB, arow, brow, 2, h);
+        mfma_block(acc, f1);
+        sched_interleave<NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        // k block 2: also park the next tile in the other LDS buffer
+        read_frags<A_KC, B_KC>(f1, cA, cB, arow, brow, 3, h);
+        store_tile<A_KC>(nA, ra, tid);
+        store_tile<B_KC>(nB, rb, tid);
+        mfma_block(acc, f0);
+        sched_interleave<NR, 8, 0x200, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // k block 3: its operands are already in registers; prefetch k block 0 of the next tile
+        read_frags<A_KC, B_KC>(f0, nA, nB, arow, brow, 0, h);
+        mfma_block(acc, f1);
+        sched_interleave<NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ktiles > 0) {  // last tile: nothing left to prefetch
+        const float* cA = smem + ((ktiles - 1) & 1) * STAGE;
+        const float* cB = cA + BOFF;
+        read_frags<A_KC, B_KC>(f1, cA, cB, arow, brow, 1, h);
+        mfma_block(acc, f0);
+        sched_interleave<NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags<A_KC, B_KC>(f0, cA, cB, arow, brow, 2, h);
+        mfma_block(acc, f1);
+        sched_interleave<NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags<A_KC, B_KC>(f1, cA, cB, arow, brow, 3, h);
+        mfma_block(acc, f0);
+        sched_interleave<NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(acc, f1);
+    }
+
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if (interior)
+        epilogue<EPI, false>(p, acc, m0, n0, wm, wn, h, l32, tc.split);
+    else
+        epilogue<EPI, true>(p, acc, m0, n0, wm, wn, h, l32, tc.split);
+}
+
+int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
 
 // ---- host-side launch --------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
@@ -233,7 +430,16 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream) {
     const long long total = (long long)p.tiles_m * p.tiles_n * p.splits;
     INR_REQUIRE(total > 0 && total < (1ll << 31), INR_E_INVALID, "gemm grid out of range (%lld blocks)", total);
     dim3 grid((unsigned)total), block(NTHREADS);
-    if (vec)
+    // fast path: 16-B aligned float4 traffic, K-tiles never straddle the contiguous axis of a k-contiguous
+    // operand, and every byte offset inside one block's SRD stays below 2^31
+    const long long a_span = A_KC ? (long long)BM * p.lda : (long long)p.k_per_split * p.lda;
+    const long long b_span = B_KC ? (long long)BN * p.ldb : (long long)p.k_per_split * p.ldb;
+    const bool fast = vec && !g_force_generic && (!A_KC || p.K % BK == 0) && (!B_KC || p.K % BK == 0) &&
+                      (a_span + (long long)BK * p.lda) * 4 < (1ll << 31) &&
+                      (b_span + (long long)BK * p.ldb) * 4 < (1ll << 31);
+    if (fast)
+        hipLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC, EPI>), grid, block, 0, stream, p);
+    else if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI, true>), grid, block, 0, stream, p);
     else
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI, false>), grid, block, 0, stream, p);
@@ -256,6 +462,7 @@ int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, c
     p.splits = 1;
     p.k_per_split = (in_f + BK - 1) / BK * BK;
     p.slab_stride = 0;
+    p.a_elems = (long long)n * in_f; p.b_elems = (long long)out_f * in_f; p.c_elems = (long long)n * out_f;
     const bool vec = vec_ok(x, W, in_f, in_f, in_f, in_f);
     ProfScope ps(KC_GEMM_FWD, stream);
     if (dact) return launch_gemm<true, true, EPI_SINE_STASH>(p, vec, stream);
@@ -273,6 +480,7 @@ int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float
     p.splits = 1;
     p.k_per_split = (out_f + BK - 1) / BK * BK;
     p.slab_stride = 0;
+    p.a_elems = (long long)n * out_f; p.b_elems = (long long)out_f * in_f; p.c_elems = (long long)n * in_f;
     // A k-contig: needs K%4; B n-contig: needs N%4 (a float4 runs along n)
     const bool vec = vec_ok(dz, W, out_f, in_f, out_f, in_f);
     ProfScope ps(KC_GEMM_DX, stream);
@@ -304,6 +512,7 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
     const long long ksteps = (n + BK - 1) / BK;
     p.k_per_split = (int)((ksteps + splits - 1) / splits) * BK;
     p.slab_stride = (long long)out_f * in_f;
+    p.a_elems = (long long)n * out_f; p.b_elems = (long long)n * in_f; p.c_elems = (long long)splits * out_f * in_f;
     const bool vec = vec_ok(dz, x, out_f, in_f, out_f, in_f);
     ProfScope ps(KC_GEMM_DW, stream);
     return launch_gemm<false, false, EPI_PLAIN>(p, vec, stream);
