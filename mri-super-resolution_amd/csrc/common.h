@@ -90,6 +90,46 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
     c = ((q + 1) & 2) ? -c0 : c0;
 }
 
+// Two-at-a-time form of sincos_f32 for the GEMM epilogues: the reduction and both polynomials are written
+// on float2 so hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (half the VALU instructions); quadrant fix-up by
+// sign-bit xor.  Same constants and operation order per element as sincos_f32 => identical results.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sincos_f32x2(f32x2_t x, f32x2_t& s, f32x2_t& c) {
+    if (__builtin_expect(!(fabsf(x[0]) < 65536.0f && fabsf(x[1]) < 65536.0f), 0)) {
+        float s0, c0, s1, c1;
+        sincos_f32(x[0], s0, c0);
+        sincos_f32(x[1], s1, c1);
+        s = f32x2_t{s0, s1};
+        c = f32x2_t{c0, c1};
+        return;
+    }
+    const f32x2_t t = x * 0.636619772367581343f;
+    f32x2_t kf;
+    kf[0] = rintf(t[0]);
+    kf[1] = rintf(t[1]);
+    const f32x2_t nk = -kf;
+    f32x2_t r = __builtin_elementwise_fma(nk, (f32x2_t)(1.57079637050628662109e+00f), x);
+    r = __builtin_elementwise_fma(nk, (f32x2_t)(-4.37113882867379288655e-08f), r);
+    r = __builtin_elementwise_fma(nk, (f32x2_t)(-1.71512451000588187280e-15f), r);
+    const f32x2_t u = r * r;
+    f32x2_t ps = __builtin_elementwise_fma((f32x2_t)(2.7181986297364347e-06f), u, (f32x2_t)(-0.00019839320157188922f));
+    ps = __builtin_elementwise_fma(ps, u, (f32x2_t)(0.008333329111337662f));
+    ps = __builtin_elementwise_fma(ps, u, (f32x2_t)(-0.1666666716337204f));
+    const f32x2_t sr = __builtin_elementwise_fma(r * u, ps, r);
+    f32x2_t pc = __builtin_elementwise_fma((f32x2_t)(-2.7208204755879706e-07f), u, (f32x2_t)(2.479949216649402e-05f));
+    pc = __builtin_elementwise_fma(pc, u, (f32x2_t)(-0.0013888883404433727f));
+    pc = __builtin_elementwise_fma(pc, u, (f32x2_t)(0.0416666679084301f));
+    const f32x2_t cr = __builtin_elementwise_fma(u * u, pc, __builtin_elementwise_fma((f32x2_t)(-0.5f), u, (f32x2_t)(1.0f)));
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const unsigned q = static_cast<unsigned>(static_cast<int>(kf[e]));
+        const float s0 = (q & 1u) ? cr[e] : sr[e];
+        const float c0 = (q & 1u) ? sr[e] : cr[e];
+        s[e] = __uint_as_float(__float_as_uint(s0) ^ ((q & 2u) << 30));
+        c[e] = __uint_as_float(__float_as_uint(c0) ^ (((q + 1u) & 2u) << 30));
+    }
+}
+
 // bit-exact torch.linspace(-1, 1, n)[i] in fp32 (oracle/inr_oracle.py: linspace_pm1)
 __device__ __forceinline__ float linspace_pm1(int64_t i, int64_t n) {
     if (n <= 1) return -1.0f;

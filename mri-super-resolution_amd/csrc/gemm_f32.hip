@@ -308,6 +308,77 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
+// NOTE: the row offset is folded into the VGPR offset and soffset stays the constant 0.  With an SGPR soffset
+// a 16-byte buffer store reads its data registers late, and on gfx950/ROCm 7.2 hipcc let the next VALU
+// instruction overwrite them (observed: lanes 12-15 of every 16 stored the FOLLOWING store's second dword).
+__device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t srd, int voff, int row_off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), srd, voff + row_off, 0, 0);
+}
+
+// Epilogue of the pipelined kernel.  Each wave parks its 64x64 accumulator sub-tile in its own 16 KB of
+// the (now idle) operand LDS and reads it back row-contiguous, so the activation is applied to float4s
+// (packed-math sincos) and every global access is a 16-byte buffer op: 16 stores per output array per wave
+// instead of 64 dword stores, out-of-range rows/columns dropped by the SRD bounds check (no branches).
+//   q-th float4 of a lane: row = 4q + lane/16, cols = 4*(lane%16) .. +3 of the wave's sub-tile.
+struct EpiAddr {
+    __amdgpu_buffer_rsrc_t srdC, srdC2, srdMul;
+    int voff;       // byte offset of the lane's first float4 inside the block's output window
+    int row_step;   // bytes between q and q+1 (4 rows)
+};
+
+template <int EPI>
+__device__ __forceinline__ EpiAddr epi_addr(const GemmParams& p, int m0, int n0, int wm, int wn, int lane, int split) {
+    EpiAddr a;
+    const long long first = (long long)split * p.slab_stride + (long long)m0 * p.ldc + n0;
+    const long long c_end = (p.splits > 1 || p.slab_stride) ? (long long)(split + 1) * p.slab_stride : p.c_elems;
+    const long long bytes = min(c_end - first, (long long)BM * p.ldc) * 4;   // this block's 128-row window only
+    a.srdC = make_srd(p.C + first, bytes);
+    a.srdC2 = make_srd(EPI == EPI_SINE_STASH ? p.C2 + first : p.C, EPI == EPI_SINE_STASH ? bytes : 0);
+    a.srdMul = make_srd(EPI == EPI_MUL ? p.mul + first : p.A, EPI == EPI_MUL ? bytes : 0);
+    const int row = wm * 64 + (lane >> 4), col = wn * 64 + (lane & 15) * 4;
+    // a lane whose columns fall outside N is pushed out of the SRD range: its loads read 0, its stores drop
+    a.voff = (n0 + col < p.N) ? (row * p.ldc + col) * 4 : 0x7FFFFF00;
+    a.row_step = 4 * p.ldc * 4;
+    return a;
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x16 (&acc)[2][2], float* __restrict__ sub,
+                                                const EpiAddr& a, const f32x4 (&mulreg)[16], int n0, int wn, int lane) {
+    const int h = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sub[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + l32] = acc[i][j][r];
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
+        const int col = n0 + wn * 64 + (lane & 15) * 4;
+        if (p.bias && col < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
+    }
+    const float* rd = sub + (lane >> 4) * 64 + (lane & 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
+        const int so = q * a.row_step;
+        if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
+            const f32x4 z = p.omega * (v + bias);
+            f32x2_t s01, c01, s23, c23;
+            sincos_f32x2(f32x2_t{z[0], z[1]}, s01, c01);
+            sincos_f32x2(f32x2_t{z[2], z[3]}, s23, c23);
+            buf_store4(f32x4{s01[0], s01[1], s23[0], s23[1]}, a.srdC, a.voff, so);
+            if (EPI == EPI_SINE_STASH)
+                buf_store4(p.omega * f32x4{c01[0], c01[1], c23[0], c23[1]}, a.srdC2, a.voff, so);
+        } else if (EPI == EPI_MUL) {
+            buf_store4(v * mulreg[q], a.srdC, a.voff, so);
+        } else {
+            buf_store4(v, a.srdC, a.voff, so);
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (TileSize<A_KC>::floats + TileSize<B_KC>::floats)];
@@ -328,8 +399,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
     // block-local SRDs: base at the tile's first element, extent to the end of the operand
     const long long a_first = A_KC ? ((long long)m0 * p.lda + k_begin) : ((long long)k_begin * p.lda + m0);
     const long long b_first = B_KC ? ((long long)n0 * p.ldb + k_begin) : ((long long)k_begin * p.ldb + n0);
-    const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A + a_first, (p.a_elems - a_first) * 4);
-    const __amdgpu_buffer_rsrc_t srdB = make_srd(p.B + b_first, (p.b_elems - b_first) * 4);
+    // extent: what this block may touch, never past the end of the operand (reads beyond return 0)
+    const long long a_span = A_KC ? (long long)BM * p.lda : (long long)(k_end - k_begin) * p.lda;
+    const long long b_span = B_KC ? (long long)BN * p.ldb : (long long)(k_end - k_begin) * p.ldb;
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A + a_first, min(p.a_elems - a_first, a_span) * 4);
+    const __amdgpu_buffer_rsrc_t srdB = make_srd(p.B + b_first, min(p.b_elems - b_first, b_span) * 4);
     const int a_step = (A_KC ? BK : BK * p.lda) * 4;  // bytes per K-tile
     const int b_step = (B_KC ? BK : BK * p.ldb) * 4;
     int va[4], vb[4];
@@ -395,6 +469,12 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
         sched_interleave<NR, 0, 0x020, 0>();
         __builtin_amdgcn_sched_barrier(0);
     }
+    const EpiAddr ea = epi_addr<EPI>(p, m0, n0, wm, wn, lane, tc.split);
+    f32x4 mulreg[16];
+    if (EPI == EPI_MUL) {  // the element-wise factor of the epilogue is fetched under the last tile's MFMAs
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mulreg[q] = buf_load4(ea.srdMul, ea.voff, q * ea.row_step);
+    }
     if (ktiles > 0) {  // last tile: nothing left to prefetch
         const float* cA = smem + ((ktiles - 1) & 1) * STAGE;
         const float* cB = cA + BOFF;
@@ -413,11 +493,8 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
         mfma_block(acc, f1);
     }
 
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (interior)
-        epilogue<EPI, false>(p, acc, m0, n0, wm, wn, h, l32, tc.split);
-    else
-        epilogue<EPI, true>(p, acc, m0, n0, wm, wn, h, l32, tc.split);
+    __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue staging area
+    epilogue_staged<EPI>(p, acc, smem + wave * 4096, ea, mulreg, n0, wn, lane);
 }
 
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
