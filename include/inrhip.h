@@ -103,15 +103,21 @@ int inr_mse_loss_grad(float* gy, float* loss, const float* y, const float* t, co
 
 /* ---- a-6: backward pieces (what autograd runs for SRDWI.py:58-59,83) -----------------------------
  * head:   dz_last[n][hidden] = (gy[n][out] @ W_head[out][hidden]) * dact_last   (in place over dact ok)
- *         gW_head[out][hidden] = gy^T a_last ; gb_head[out] = colsum(gy) */
+ *         gW_head[out][hidden] = gy^T a_last ; gb_head[out] = colsum(gy)
+ *         gb_last[hidden] (nullable, needs dz_last) = colsum(dz_last): the bias gradient of the last sine
+ *         layer, produced by the same pass (one fused kernel when out_features == 1). */
 size_t inr_head_backward_workspace_bytes(int64_t n, int hidden, int out_features);
-int inr_linear_head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
-                             const float* dact_last, const float* W, int64_t n, int hidden, int out_features,
-                             void* workspace, size_t workspace_bytes, void* stream);
+int inr_linear_head_backward(float* dz_last, float* gW, float* gb, float* gb_last, const float* gy,
+                             const float* a_last, const float* dact_last, const float* W, int64_t n, int hidden,
+                             int out_features, void* workspace, size_t workspace_bytes, void* stream);
 /* input grad through one sine layer: dz_prev[n][in] = (dz[n][out] @ W[out][in]) * dact_prev[n][in]
- * (dz_prev may alias dact_prev).  With dact_prev == NULL writes the plain product dz @ W. */
-int inr_sine_layer_backward_input(float* dz_prev, const float* dz, const float* W, const float* dact_prev,
-                                  int64_t n, int in_features, int out_features, void* stream);
+ * (dz_prev may alias dact_prev).  With dact_prev == NULL writes the plain product dz @ W.
+ * gb_prev[in] (nullable) = colsum(dz_prev), the bias gradient of the layer below, accumulated in the GEMM
+ * epilogue; it needs the workspace (otherwise workspace may be NULL). */
+size_t inr_sine_layer_backward_input_workspace_bytes(int64_t n, int in_features);
+int inr_sine_layer_backward_input(float* dz_prev, float* gb_prev, const float* dz, const float* W,
+                                  const float* dact_prev, int64_t n, int in_features, int out_features,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 /* parameter grads: gW[out][in] = dz^T x ; gb[out] = colsum(dz).  Split over rows + fixed-order reduce. */
 size_t inr_linear_param_grad_workspace_bytes(int64_t n, int in_features, int out_features);
 int inr_linear_param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n,

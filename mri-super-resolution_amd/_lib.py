@@ -51,10 +51,11 @@ SIGNATURES = {
     "inr_mse_loss_grad": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_size_t,
                                     c_stream]),
     "inr_head_backward_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
-    "inr_linear_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
+    "inr_linear_head_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64,
                                            C.c_int, C.c_int, C.c_void_p, C.c_size_t, c_stream]),
-    "inr_sine_layer_backward_input": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int,
-                                                c_stream]),
+    "inr_sine_layer_backward_input_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "inr_sine_layer_backward_input": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_size_t, c_stream]),
     "inr_linear_param_grad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "inr_linear_param_grad": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                         C.c_size_t, c_stream]),

@@ -27,6 +27,7 @@ struct ProfState {
     std::vector<hipEvent_t> pool;                    // recycled events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[KC_COUNT];
     hipEvent_t open[KC_COUNT] = {nullptr, nullptr, nullptr, nullptr};
+    int depth[KC_COUNT] = {0, 0, 0, 0};
     hipEvent_t get() {
         if (!pool.empty()) {
             hipEvent_t e = pool.back();
@@ -40,14 +41,17 @@ struct ProfState {
 };
 static ProfState g_prof;
 bool prof_enabled() { return g_prof.enabled; }
+// scopes of one class may nest (a launcher calling another launcher): only the outermost pair is recorded
 void prof_begin(int kc, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.depth[kc]++ > 0) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
     g_prof.open[kc] = e;
 }
 void prof_end(int kc, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (--g_prof.depth[kc] > 0) return;
     hipEvent_t e = g_prof.get();
     (void)hipEventRecord(e, s);
     g_prof.spans[kc].push_back({g_prof.open[kc], e});
@@ -57,8 +61,9 @@ void prof_end(int kc, hipStream_t s) {
 // ---- kernels implemented in gemm_f32.hip / kernels.hip ------------------------------------------------
 int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
                       int in_f, int out_f, float omega, hipStream_t stream);
+int input_grad_colsum_rows(int64_t n);
 int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
-                    int out_f, hipStream_t stream);
+                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream);
 int param_grad_splits(int64_t n, int in_f, int out_f);
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
                           int out_f, hipStream_t stream);
@@ -72,10 +77,15 @@ int launch_mse(float* gy, float* loss, const float* y, const float* t, const flo
                float* partial, hipStream_t st);
 int launch_head_dz(float* dz, const float* gy, const float* W, const float* dact, int64_t n, int hidden,
                    int out_f, hipStream_t st);
-int64_t colsum_chunks(int64_t n, int C);
+int64_t colsum_ws_floats(int64_t n, int C, int G);
 int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab,
                   hipStream_t st);
-int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, hipStream_t st);
+int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st);
+bool head_fused_ok(int hidden, int out_f, const void* a, const void* b, const void* c, const void* d);
+int64_t head_fused_blocks(int64_t n);
+int launch_head_bwd_fused(float* dz, float* slab_b, float* slab_w, const float* gy, const float* W, const float* a,
+                          const float* dact, int64_t n, int hidden, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr, double b1,
                 double b2, double eps, hipStream_t st);
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
@@ -118,40 +128,81 @@ static Layout make_layout(const inr_siren_desc_t* d) {
     return L;
 }
 
+static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
 static size_t param_grad_ws_floats(int64_t n, int in_f, int out_f) {
-    const size_t slabs = (size_t)param_grad_splits(n, in_f, out_f) * (size_t)in_f * out_f;
-    const size_t col = (size_t)colsum_chunks(n, out_f) * (size_t)out_f;
-    return slabs > col ? slabs : col;
+    const int splits = param_grad_splits(n, in_f, out_f);
+    const size_t len = (size_t)in_f * out_f;
+    const size_t slabs = (size_t)splits * len + (size_t)reduce_tmp_floats(splits, (int64_t)len);
+    return max2(slabs, (size_t)colsum_ws_floats(n, out_f, 1));
 }
 
-// gW = dz^T x, gb = colsum(dz); ws holds max(slabs, colsum chunks)
+// gW = dz^T x (row-split slabs + fixed-order reduce); gb = colsum(dz) when requested
 static int param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n, int in_f, int out_f,
                       float* ws, hipStream_t st) {
     const int splits = param_grad_splits(n, in_f, out_f);
+    const int64_t len = (int64_t)in_f * out_f;
     if (int rc = gemm_param_grad_slabs(ws, splits, dz, x, n, in_f, out_f, st)) return rc;
-    if (int rc = launch_reduce_slabs(gW, ws, splits, (int64_t)in_f * out_f, st)) return rc;
+    if (int rc = launch_reduce_slabs(gW, ws, splits, len, ws + (int64_t)splits * len, st)) return rc;
     if (gb) {
         if (int rc = launch_colsum(gb, dz, nullptr, n, out_f, 1, ws, st)) return rc;
     }
     return 0;
 }
 
-static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
-    const size_t a = (size_t)colsum_chunks(n, hidden) * (size_t)out_f * hidden;
-    const size_t b = (size_t)colsum_chunks(n, out_f) * (size_t)out_f;
-    return a > b ? a : b;
+static size_t input_grad_ws_floats(int64_t n, int in_f) {
+    const int64_t rows = input_grad_colsum_rows(n);
+    return max2((size_t)(rows * in_f + reduce_tmp_floats(rows, in_f)), (size_t)colsum_ws_floats(n, in_f, 1));
 }
 
-static int head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
+// dz_prev = (dz W) * dact_prev; gb_prev (nullable) = colsum(dz_prev), fused into the GEMM epilogue when the
+// fast kernel runs, otherwise a separate column-sum pass
+static int input_grad(float* dz_prev, float* gb_prev, const float* dz, const float* W, const float* dact_prev,
+                      int64_t n, int in_f, int out_f, float* ws, hipStream_t st) {
+    int slab_rows = 0;
+    float* slab = (gb_prev && dact_prev) ? ws : nullptr;
+    if (int rc = gemm_input_grad(dz_prev, dz, W, dact_prev, n, in_f, out_f, slab, &slab_rows, st)) return rc;
+    if (!gb_prev) return 0;
+    if (slab_rows > 0) return launch_reduce_slabs(gb_prev, ws, slab_rows, in_f, ws + (int64_t)slab_rows * in_f, st);
+    return launch_colsum(gb_prev, dz_prev, nullptr, n, in_f, 1, ws, st);
+}
+
+static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
+    const int64_t blocks = head_fused_blocks(n);
+    const size_t fused = (size_t)(2 * blocks * hidden + reduce_tmp_floats(blocks, hidden));
+    const size_t a = (size_t)colsum_ws_floats(n, hidden, out_f);
+    const size_t b = (size_t)colsum_ws_floats(n, out_f, 1);
+    return max2(fused, max2(a, b));
+}
+
+// head backward: dz_last = (gy W) * dact_last, gW/gb of the head, and (optionally) gb_last = colsum(dz_last),
+// the bias gradient of the last sine layer.  One fused pass when out_features == 1.
+static int head_backward(float* dz_last, float* gW, float* gb, float* gb_last, const float* gy, const float* a_last,
                          const float* dact_last, const float* W, int64_t n, int hidden, int out_f, float* ws,
                          hipStream_t st) {
+    if (dz_last && gW && dact_last && head_fused_ok(hidden, out_f, dz_last, a_last, dact_last, W)) {
+        const int64_t blocks = head_fused_blocks(n);
+        float* slab_b = ws;
+        float* slab_w = ws + blocks * hidden;
+        float* tmp = ws + 2 * blocks * hidden;
+        if (int rc = launch_head_bwd_fused(dz_last, slab_b, slab_w, gy, W, a_last, dact_last, n, hidden, st)) return rc;
+        if (gb_last) {
+            if (int rc = launch_reduce_slabs(gb_last, slab_b, (int)blocks, hidden, tmp, st)) return rc;
+        }
+        if (int rc = launch_reduce_slabs(gW, slab_w, (int)blocks, hidden, tmp, st)) return rc;
+        if (gb) return launch_colsum(gb, gy, nullptr, n, out_f, 1, ws, st);
+        return 0;
+    }
     if (gW) {
         if (int rc = launch_colsum(gW, a_last, gy, n, hidden, out_f, ws, st)) return rc;
     }
     if (gb) {
         if (int rc = launch_colsum(gb, gy, nullptr, n, out_f, 1, ws, st)) return rc;
     }
-    if (dz_last) return launch_head_dz(dz_last, gy, W, dact_last, n, hidden, out_f, st);
+    if (dz_last) {
+        if (int rc = launch_head_dz(dz_last, gy, W, dact_last, n, hidden, out_f, st)) return rc;
+        if (gb_last) return launch_colsum(gb_last, dz_last, nullptr, n, hidden, 1, ws, st);
+    }
     return 0;
 }
 
@@ -236,24 +287,34 @@ size_t inr_head_backward_workspace_bytes(int64_t n, int hidden, int out_features
     return head_backward_ws_floats(n > 0 ? n : 1, hidden, out_features) * sizeof(float);
 }
 
-int inr_linear_head_backward(float* dz_last, float* gW, float* gb, const float* gy, const float* a_last,
-                             const float* dact_last, const float* W, int64_t n, int hidden, int out_features,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+int inr_linear_head_backward(float* dz_last, float* gW, float* gb, float* gb_last, const float* gy,
+                             const float* a_last, const float* dact_last, const float* W, int64_t n, int hidden,
+                             int out_features, void* workspace, size_t workspace_bytes, void* stream) {
     INR_REQUIRE(gy && a_last && W, INR_E_INVALID, "inr_linear_head_backward: null pointer");
     INR_REQUIRE(n >= 1 && hidden >= 1 && out_features >= 1, INR_E_INVALID, "inr_linear_head_backward: bad sizes");
     INR_REQUIRE(workspace && workspace_bytes >= inr_head_backward_workspace_bytes(n, hidden, out_features),
                 INR_E_WORKSPACE, "inr_linear_head_backward: workspace too small");
-    return head_backward(dz_last, gW, gb, gy, a_last, dact_last, W, n, hidden, out_features, (float*)workspace,
-                         (hipStream_t)stream);
+    INR_REQUIRE(!gb_last || dz_last, INR_E_INVALID, "inr_linear_head_backward: gb_last needs dz_last");
+    return head_backward(dz_last, gW, gb, gb_last, gy, a_last, dact_last, W, n, hidden, out_features,
+                         (float*)workspace, (hipStream_t)stream);
 }
 
-int inr_sine_layer_backward_input(float* dz_prev, const float* dz, const float* W, const float* dact_prev, int64_t n,
-                                  int in_features, int out_features, void* stream) {
+size_t inr_sine_layer_backward_input_workspace_bytes(int64_t n, int in_features) {
+    return input_grad_ws_floats(n > 0 ? n : 1, in_features) * sizeof(float);
+}
+
+int inr_sine_layer_backward_input(float* dz_prev, float* gb_prev, const float* dz, const float* W,
+                                  const float* dact_prev, int64_t n, int in_features, int out_features,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     INR_REQUIRE(dz_prev && dz && W, INR_E_INVALID, "inr_sine_layer_backward_input: null pointer");
     INR_REQUIRE(n >= 0 && n <= MAX_ROWS && in_features >= 1 && out_features >= 1, INR_E_INVALID,
                 "inr_sine_layer_backward_input: bad sizes");
     if (n == 0) return 0;
-    return gemm_input_grad(dz_prev, dz, W, dact_prev, n, in_features, out_features, (hipStream_t)stream);
+    if (gb_prev)
+        INR_REQUIRE(workspace && workspace_bytes >= inr_sine_layer_backward_input_workspace_bytes(n, in_features),
+                    INR_E_WORKSPACE, "inr_sine_layer_backward_input: workspace too small for gb_prev");
+    return input_grad(dz_prev, gb_prev, dz, W, dact_prev, n, in_features, out_features, (float*)workspace,
+                      (hipStream_t)stream);
 }
 
 size_t inr_linear_param_grad_workspace_bytes(int64_t n, int in_features, int out_features) {
@@ -390,8 +451,8 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     c.out_b = round_up((size_t)n * d->out_features * sizeof(float), 256);
     size_t scratch = head_backward_ws_floats(n, d->hidden_features, d->out_features);
     for (int l = 0; l < L.n_sine; ++l) {
-        const size_t s = param_grad_ws_floats(n, L.fan_in[l], L.fan_out[l]);
-        if (s > scratch) scratch = s;
+        scratch = max2(scratch, param_grad_ws_floats(n, L.fan_in[l], L.fan_out[l]));
+        if (l > 0) scratch = max2(scratch, input_grad_ws_floats(n, L.fan_in[l]));
     }
     const size_t mse = (size_t)mse_blocks((int64_t)n * d->out_features) + 1;
     if (mse > scratch) scratch = mse;
@@ -449,16 +510,19 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
         float* loss_dst = losses ? (losses + it) : loss_sink;
         if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st)) return rc;
         // backward: head, then sine layers from last to first; dz overwrites dact in place
-        if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head], gy, act[head],
-                                   dact[head - 1], params + L.w_off[head], n, H, O, scratch, st))
+        // (bias gradients ride along: the head pass yields gb of the last sine layer, every input-grad GEMM
+        //  yields gb of the layer below from its epilogue)
+        if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
+                                   grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
+                                   H, O, scratch, st))
             return rc;
         for (int l = L.n_sine - 1; l >= 0; --l) {
-            if (int rc = param_grad(grads + L.w_off[l], grads + L.b_off[l], dact[l], act[l], n, L.fan_in[l],
-                                    L.fan_out[l], scratch, st))
+            if (int rc = param_grad(grads + L.w_off[l], nullptr, dact[l], act[l], n, L.fan_in[l], L.fan_out[l],
+                                    scratch, st))
                 return rc;
             if (l > 0) {
-                if (int rc = gemm_input_grad(dact[l - 1], dact[l], params + L.w_off[l], dact[l - 1], n, L.fan_in[l],
-                                             L.fan_out[l], st))
+                if (int rc = input_grad(dact[l - 1], grads + L.b_off[l - 1], dact[l], params + L.w_off[l], dact[l - 1],
+                                        n, L.fan_in[l], L.fan_out[l], scratch, st))
                     return rc;
             }
         }

@@ -44,6 +44,7 @@ struct GemmParams {
     float* C2;   // EPI_SINE_STASH: dact
     const float* bias;  // EPI_SINE*: per-column bias (nullable)
     const float* mul;   // EPI_MUL: element-wise factor, same layout as C (nullable -> plain)
+    float* colsum;      // EPI_MUL fast path: slab [2*tiles_m][N] of per-64-row column sums of C (nullable)
     int M, N, K;
     int lda, ldb, ldc;
     float omega;
@@ -344,7 +345,8 @@ __device__ __forceinline__ EpiAddr epi_addr(const GemmParams& p, int m0, int n0,
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x16 (&acc)[2][2], float* __restrict__ sub,
-                                                const EpiAddr& a, const f32x4 (&mulreg)[16], int n0, int wn, int lane) {
+                                                const EpiAddr& a, const f32x4 (&mulreg)[16], int n0, int wn, int lane,
+                                                int slab_row) {
     const int h = lane >> 5, l32 = lane & 31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -359,6 +361,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
         if (p.bias && col < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
     }
     const float* rd = sub + (lane >> 4) * 64 + (lane & 15) * 4;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
@@ -372,10 +375,23 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
             if (EPI == EPI_SINE_STASH)
                 buf_store4(p.omega * f32x4{c01[0], c01[1], c23[0], c23[1]}, a.srdC2, a.voff, so);
         } else if (EPI == EPI_MUL) {
-            buf_store4(v * mulreg[q], a.srdC, a.voff, so);
+            const f32x4 o = v * mulreg[q];   // rows past M: v == 0 and mulreg == 0, so they add nothing below
+            csum += o;
+            buf_store4(o, a.srdC, a.voff, so);
         } else {
             buf_store4(v, a.srdC, a.voff, so);
         }
+    }
+    if (EPI == EPI_MUL && p.colsum) {
+        // bias gradient of the layer below = column sums of this tile: 16 rows per lane, then the 4 lanes that
+        // share a column group (lane, lane^16, lane^32, lane^48) in a fixed order -> one slab row per wave
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            csum[e] += __shfl_xor(csum[e], 16, 64);
+            csum[e] += __shfl_xor(csum[e], 32, 64);
+        }
+        const int col = n0 + wn * 64 + (lane & 15) * 4;
+        if (lane < 16 && col < p.N) *reinterpret_cast<f32x4*>(p.colsum + (long long)slab_row * p.N + col) = csum;
     }
 }
 
@@ -494,14 +510,14 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
     }
 
     __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue staging area
-    epilogue_staged<EPI>(p, acc, smem + wave * 4096, ea, mulreg, n0, wn, lane);
+    epilogue_staged<EPI>(p, acc, smem + wave * 4096, ea, mulreg, n0, wn, lane, tc.tile_m * 2 + wm);
 }
 
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
 
 // ---- host-side launch --------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
-static int launch_gemm(GemmParams p, bool vec, hipStream_t stream) {
+static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fast = nullptr) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const long long total = (long long)p.tiles_m * p.tiles_n * p.splits;
@@ -514,6 +530,7 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream) {
     const bool fast = vec && !g_force_generic && (!A_KC || p.K % BK == 0) && (!B_KC || p.K % BK == 0) &&
                       (a_span + (long long)BK * p.lda) * 4 < (1ll << 31) &&
                       (b_span + (long long)BK * p.ldb) * 4 < (1ll << 31);
+    if (used_fast) *used_fast = fast;
     if (fast)
         hipLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC, EPI>), grid, block, 0, stream, p);
     else if (vec)
@@ -547,8 +564,12 @@ int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, c
 }
 
 // dz_prev[n][in] = (dz[n][out] @ W[out][in]) * mul[n][in]   (mul nullable)
+// colsum_slab (nullable, needs mul): receives [*slab_rows][in] partial column sums of dz_prev when the fast
+// kernel ran (*slab_rows = 2*ceil(n/128)); *slab_rows = 0 means the caller must run its own column sum.
+int input_grad_colsum_rows(int64_t n) { return 2 * (int)((n + BM - 1) / BM); }
+
 int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
-                    int out_f, hipStream_t stream) {
+                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream) {
     GemmParams p{};
     p.A = dz; p.B = W; p.C = dz_prev; p.C2 = nullptr; p.bias = nullptr; p.mul = mul;
     p.M = (int)n; p.N = in_f; p.K = out_f;
@@ -561,7 +582,14 @@ int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float
     // A k-contig: needs K%4; B n-contig: needs N%4 (a float4 runs along n)
     const bool vec = vec_ok(dz, W, out_f, in_f, out_f, in_f);
     ProfScope ps(KC_GEMM_DX, stream);
-    if (mul) return launch_gemm<true, false, EPI_MUL>(p, vec, stream);
+    if (slab_rows) *slab_rows = 0;
+    if (mul) {
+        p.colsum = (in_f % 4 == 0) ? colsum_slab : nullptr;
+        bool fast = false;
+        const int rc = launch_gemm<true, false, EPI_MUL>(p, vec, stream, &fast);
+        if (rc == 0 && fast && p.colsum && slab_rows) *slab_rows = input_grad_colsum_rows(n);
+        return rc;
+    }
     return launch_gemm<true, false, EPI_PLAIN>(p, vec, stream);
 }
 

@@ -158,6 +158,49 @@ __global__ void __launch_bounds__(256) head_dz_kernel(float* __restrict__ dz, co
     }
 }
 
+// ---- fused head backward (out_features == 1, hidden/4 divides 256) ---------------------------------------
+// One pass over the last sine layer's rows does everything the head needs:
+//   dz[row][k]  = gy[row] * W[k] * dact[row][k]                      (in place over dact is fine)
+//   slab_b[blk][k] = sum_{rows of blk} dz[row][k]                    (bias grad of the last sine layer)
+//   slab_w[blk][k] = sum_{rows of blk} gy[row] * a[row][k]           (weight grad of the head)
+// float4 per thread, column group fixed per thread so the sums stay in registers; rows of a block are
+// visited in a fixed order and the RP row-phases are combined through LDS in a fixed order (deterministic).
+constexpr int HEAD_ROWS_PER_BLOCK = 256;
+__global__ void __launch_bounds__(256) head_bwd_fused_kernel(float* dz, float* __restrict__ slab_b,
+                                                             float* __restrict__ slab_w, const float* __restrict__ gy,
+                                                             const float* __restrict__ W, const float* __restrict__ a,
+                                                             const float* dact, int64_t n, int hidden) {
+    __shared__ f32x4 red[2][256];
+    const int Q = hidden >> 2;           // float4 groups per row (divides 256)
+    const int RP = 256 / Q;              // rows per pass
+    const int c4 = threadIdx.x % Q, rsub = threadIdx.x / Q;
+    const int64_t r0 = (int64_t)blockIdx.x * HEAD_ROWS_PER_BLOCK;
+    const int64_t r1 = min(n, r0 + HEAD_ROWS_PER_BLOCK);
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + 4 * c4);
+    f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sw = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = r0 + rsub; r < r1; r += RP) {
+        const float g = gy[r];
+        const int64_t off = r * hidden + 4 * c4;
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dact + off);
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(a + off);
+        const f32x4 o = (g * w4) * d4;
+        *reinterpret_cast<f32x4*>(dz + off) = o;
+        sb += o;
+        sw += g * a4;
+    }
+    red[0][threadIdx.x] = sb;
+    red[1][threadIdx.x] = sw;
+    __syncthreads();
+    if (rsub == 0) {
+        for (int k = 1; k < RP; ++k) {
+            sb += red[0][k * Q + c4];
+            sw += red[1][k * Q + c4];
+        }
+        *reinterpret_cast<f32x4*>(slab_b + (int64_t)blockIdx.x * hidden + 4 * c4) = sb;
+        *reinterpret_cast<f32x4*>(slab_w + (int64_t)blockIdx.x * hidden + 4 * c4) = sw;
+    }
+}
+
 // ---- weighted column sums over a row chunk ----------------------------------------------------------
 // slab[chunk][gi][c] = sum_{row in chunk} g[row][gi] * X[row][c]   (g == nullptr: G = 1, weight 1)
 // grid = (chunks, ceil(C/256)); thread = one column; rows streamed, coalesced across the block.
@@ -192,19 +235,24 @@ __global__ void __launch_bounds__(256) colsum_kernel(float* __restrict__ slab, c
     }
 }
 
-// out[i] = sum_{s < nslabs} slab[s][i]  (fixed order)
+// out[g][i] = sum_{s in group g} slab[s][i]  (fixed order; group g = slabs [g*per_group, (g+1)*per_group))
+// grid = (ceil(len/256), groups).  With groups == 1 this is the plain slab reduction.
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slab,
-                                                           int nslabs, int64_t len) {
+                                                           int nslabs, int64_t len, int per_group) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
-    float a0 = 0.f, a1 = 0.f;
-    int s = 0;
-    for (; s + 1 < nslabs; s += 2) {
+    const int s0 = blockIdx.y * per_group;
+    const int s1 = min(nslabs, s0 + per_group);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
         a0 += slab[(int64_t)s * len + i];
         a1 += slab[(int64_t)(s + 1) * len + i];
+        a2 += slab[(int64_t)(s + 2) * len + i];
+        a3 += slab[(int64_t)(s + 3) * len + i];
     }
-    if (s < nslabs) a0 += slab[(int64_t)s * len + i];
-    out[i] = a0 + a1;
+    for (; s < s1; ++s) a0 += slab[(int64_t)s * len + i];
+    out[(int64_t)blockIdx.y * len + i] = (a0 + a1) + (a2 + a3);
 }
 
 // ---- a-7: Adam (torch single-tensor formulation) ---------------------------------------------------
@@ -326,6 +374,7 @@ int launch_head_dz(float* dz, const float* gy, const float* W, const float* dact
     return 0;
 }
 
+int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
 // chunking used by the column-sum path: ~2048 blocks, at least 32 rows per chunk
 int64_t colsum_rows_per_chunk(int64_t n, int C) {
     const int64_t col_groups = (C + 255) / 256;
@@ -339,8 +388,15 @@ int64_t colsum_chunks(int64_t n, int C) {
     const int64_t rpc = colsum_rows_per_chunk(n, C);
     return (n + rpc - 1) / rpc;
 }
+int64_t colsum_ws_floats(int64_t n, int C, int G) {
+    const int64_t chunks = colsum_chunks(n, C);
+    return chunks * G * C + reduce_tmp_floats(chunks, (int64_t)G * C);
+}
 
-// out[G][C] = sum_rows g[row][gi]*X[row][c]; slab must hold colsum_chunks(n,C)*G*C floats
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st);
+int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
+
+// out[G][C] = sum_rows g[row][gi]*X[row][c]; slab must hold colsum_ws_floats(n, C, G) floats
 int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab,
                   hipStream_t st) {
     const int64_t rpc = colsum_rows_per_chunk(n, C);
@@ -350,16 +406,43 @@ int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, 
                        g, n, C, G, rpc);
     INR_LAUNCH_CHECK();
     const int64_t len = (int64_t)G * C;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(len, 256, 1 << 30)), dim3(256), 0, st, out, slab,
-                       (int)chunks, len);
+    return launch_reduce_slabs(out, slab, (int)chunks, len, slab + chunks * len, st);
+}
+
+// tall-and-narrow slab stacks (thousands of slabs of a few hundred floats) are reduced in two stages so the
+// sum is spread over many blocks; `tmp` must hold reduce_tmp_floats(nslabs, len) floats and not overlap `slab`.
+constexpr int REDUCE_GROUP = 32;
+int64_t reduce_tmp_floats(int64_t nslabs, int64_t len) {
+    return nslabs > 4 * REDUCE_GROUP ? (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP * len : 0;
+}
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st) {
+    ProfScope ps(KC_OTHER, st);
+    const unsigned gx = blocks_for(len, 256, 1 << 30);
+    if (reduce_tmp_floats(nslabs, len) == 0) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, slab, nslabs, len, nslabs);
+        INR_LAUNCH_CHECK();
+        return 0;
+    }
+    const int groups = (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, groups), dim3(256), 0, st, tmp, slab, nslabs, len, REDUCE_GROUP);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, tmp, groups, len, groups);
     INR_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, hipStream_t st) {
+// fused head backward for out_features == 1 (see head_bwd_fused_kernel)
+bool head_fused_ok(int hidden, int out_f, const void* a, const void* b, const void* c, const void* d) {
+    const int Q = hidden >> 2;
+    return out_f == 1 && hidden % 4 == 0 && Q >= 1 && Q <= 256 && 256 % Q == 0 && aligned16(a) && aligned16(b) &&
+           aligned16(c) && aligned16(d);
+}
+int64_t head_fused_blocks(int64_t n) { return (n + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK; }
+int launch_head_bwd_fused(float* dz, float* slab_b, float* slab_w, const float* gy, const float* W, const float* a,
+                          const float* dact, int64_t n, int hidden, hipStream_t st) {
     ProfScope ps(KC_OTHER, st);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks_for(len, 256, 1 << 30)), dim3(256), 0, st, out, slab, nslabs,
-                       len);
+    hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((unsigned)head_fused_blocks(n)), dim3(256), 0, st, dz, slab_b,
+                       slab_w, gy, W, a, dact, n, hidden);
     INR_LAUNCH_CHECK();
     return 0;
 }

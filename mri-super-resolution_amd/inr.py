@@ -192,15 +192,21 @@ class _SirenFn(torch.autograd.Function):
         acts, dacts, weights = saved[:n + 1], saved[n + 1:2 * n + 1], saved[2 * n + 1:]
         need_params = any(ctx.needs_input_grad[3:])
         grads = [None] * (2 * (n + 1))
-        dz, gWh, gbh = ops.linear_head_backward(gy.contiguous(), acts[n], dacts[n - 1], weights[n].contiguous(),
-                                                need_dz=True, need_param=need_params)
+        # bias gradients ride along with the passes that produce dz (head pass / input-grad GEMM epilogue)
+        dz, gWh, gbh, gb_l = ops.linear_head_backward(gy.contiguous(), acts[n], dacts[n - 1], weights[n].contiguous(),
+                                                      need_dz=True, need_param=need_params,
+                                                      need_bias_last=need_params)
         grads[2 * n], grads[2 * n + 1] = gWh, gbh
         gx = None
         for l in range(n - 1, -1, -1):
             if need_params:
-                grads[2 * l], grads[2 * l + 1] = ops.linear_param_grad(dz, acts[l])
+                grads[2 * l], _ = ops.linear_param_grad(dz, acts[l], need_bias=False)
+                grads[2 * l + 1] = gb_l
             if l > 0:
-                dz = ops.sine_layer_backward_input(dz, weights[l].contiguous(), dacts[l - 1])
+                if need_params:
+                    dz, gb_l = ops.sine_layer_backward_input(dz, weights[l].contiguous(), dacts[l - 1], need_bias=True)
+                else:
+                    dz = ops.sine_layer_backward_input(dz, weights[l].contiguous(), dacts[l - 1])
             elif ctx.needs_input_grad[0]:
                 gx = ops.sine_layer_backward_input(dz, weights[0].contiguous(), None)
         return (gx, None, None, *grads)

@@ -173,8 +173,9 @@ def mse_loss_grad(y, t, w=None):
     return loss, gy
 
 
-def linear_head_backward(gy, a_last, dact_last, W, need_dz=True, need_param=True):
-    """dz_last = (gy W) * dact_last (plain product when dact_last is None); gW, gb of the head."""
+def linear_head_backward(gy, a_last, dact_last, W, need_dz=True, need_param=True, need_bias_last=False):
+    """dz_last = (gy W) * dact_last (plain product when dact_last is None); gW, gb of the head; with
+    ``need_bias_last`` also colsum(dz_last), the bias gradient of the last sine layer."""
     _chk(gy, "gy")
     _chk(a_last, "a_last")
     _chk(W, "weight")
@@ -187,16 +188,18 @@ def linear_head_backward(gy, a_last, dact_last, W, need_dz=True, need_param=True
     dz = torch.empty((n, hidden), dtype=torch.float32, device=gy.device) if need_dz else None
     gW = torch.empty_like(W) if need_param else None
     gb = torch.empty((out_f,), dtype=torch.float32, device=gy.device) if need_param else None
+    gb_last = torch.empty((hidden,), dtype=torch.float32, device=gy.device) if (need_bias_last and need_dz) else None
     nbytes = lib().inr_head_backward_workspace_bytes(n, hidden, out_f)
     ws = _ws(nbytes, gy.device)
-    check(lib().inr_linear_head_backward(_ptr(dz), _ptr(gW), _ptr(gb), gy.data_ptr(), a_last.data_ptr(),
+    check(lib().inr_linear_head_backward(_ptr(dz), _ptr(gW), _ptr(gb), _ptr(gb_last), gy.data_ptr(), a_last.data_ptr(),
                                          _ptr(dact_last), W.data_ptr(), n, hidden, out_f, ws.data_ptr(), ws.numel(),
                                          _stream()), "inr_linear_head_backward")
-    return dz, gW, gb
+    return dz, gW, gb, gb_last
 
 
-def sine_layer_backward_input(dz, W, dact_prev, out=None):
-    """(dz @ W) * dact_prev  ->  [n, in]; `out` may alias dact_prev (in place)."""
+def sine_layer_backward_input(dz, W, dact_prev, out=None, need_bias=False):
+    """(dz @ W) * dact_prev  ->  [n, in]; `out` may alias dact_prev (in place).  With ``need_bias`` also returns
+    colsum of the result (bias gradient of the layer below) from the fused epilogue."""
     _chk(dz, "dz")
     _chk(W, "weight")
     n, fout = dz.shape
@@ -209,9 +212,16 @@ def sine_layer_backward_input(dz, W, dact_prev, out=None):
         out = torch.empty((n, fin), dtype=torch.float32, device=dz.device)
     else:
         _chk(out, "out", (n, fin))
-    check(lib().inr_sine_layer_backward_input(out.data_ptr(), dz.data_ptr(), W.data_ptr(), _ptr(dact_prev), n, fin,
-                                              fout, _stream()), "inr_sine_layer_backward_input")
-    return out
+    gb = ws = None
+    ws_ptr, ws_bytes = 0, 0
+    if need_bias:
+        gb = torch.empty((fin,), dtype=torch.float32, device=dz.device)
+        ws = _ws(lib().inr_sine_layer_backward_input_workspace_bytes(n, fin), dz.device)
+        ws_ptr, ws_bytes = ws.data_ptr(), ws.numel()
+    check(lib().inr_sine_layer_backward_input(out.data_ptr(), _ptr(gb), dz.data_ptr(), W.data_ptr(), _ptr(dact_prev), n,
+                                              fin, fout, ws_ptr, ws_bytes, _stream()),
+          "inr_sine_layer_backward_input")
+    return (out, gb) if need_bias else out
 
 
 def linear_param_grad(dz, x, need_bias=True):
