@@ -1,0 +1,74 @@
+"""CPU tests of the multi-GPU driver logic: deterministic LPT partitioning and the fixed-size metric gather,
+exercised with world_size = 2 on the gloo backend (the GPU runs use the same code over nccl/RCCL)."""
+import os
+import socket
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mri_super_resolution_amd import dist as inr_dist
+
+
+def test_lpt_partition_properties():
+    # the 11 patient volumes of the reference: z = 28 x5, 24 x3, 34 x3, 64*64*z coords each
+    costs = [64 * 64 * z for z in (28, 28, 28, 28, 28, 24, 24, 24, 34, 34, 34)]
+    plan = inr_dist.partition_fits(costs, 8)
+    assert sorted(i for jobs in plan for i in jobs) == list(range(11))          # every job exactly once
+    # three ranks take two volumes; LPT pairs each 24-slice volume with a 28-slice one: makespan 52 slices,
+    # i.e. 314/52 = 6.04x over one GPU for whole-volume packing
+    assert inr_dist.makespan(costs, plan) == 64 * 64 * 52
+    assert plan == inr_dist.partition_fits(costs, 8)                             # deterministic
+    assert inr_dist.partition_fits(costs, 1) == [sorted(range(11), key=lambda i: (-costs[i], i))]
+    assert inr_dist.partition_fits([], 3) == [[], [], []]
+    assert inr_dist.partition_fits([5.0], 4)[0] == [0]
+    with pytest.raises(ValueError):
+        inr_dist.partition_fits(costs, 0)
+
+
+def test_gather_single_process():
+    rec = {"n": 4096.0, "seconds": 1.5}
+    assert inr_dist.gather_records(rec) == [rec]
+    out = inr_dist.gather_job_records([{"id": 3.0, "psnr": 32.5}], ["id", "psnr"], 2)
+    assert out == [{"id": 3.0, "psnr": 32.5}]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        costs = [5.0, 3.0, 9.0, 1.0, 7.0]
+        plan = inr_dist.partition_fits(costs, world)
+        recs = inr_dist.gather_records({"rank": float(rank), "load": sum(costs[i] for i in plan[rank])})
+        local = [{"job": float(i), "cost": costs[i], "rank": float(rank)} for i in plan[rank]]
+        jobs = inr_dist.gather_job_records(local, ["job", "cost", "rank"], max_jobs_per_rank=4)
+        q.put((rank, plan, recs, jobs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get() for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    results.sort()
+    (r0, plan0, recs0, jobs0), (r1, plan1, recs1, jobs1) = results
+    assert plan0 == plan1 == [[2, 1, 3], [4, 0]]                    # same schedule on every rank, no communication
+    assert recs0 == recs1 == [{"load": 13.0, "rank": 0.0}, {"load": 12.0, "rank": 1.0}]
+    assert jobs0 == jobs1
+    assert sorted(j["job"] for j in jobs0) == [0.0, 1.0, 2.0, 3.0, 4.0]
+    assert {j["job"]: j["rank"] for j in jobs0} == {2.0: 0.0, 1.0: 0.0, 3.0: 0.0, 4.0: 1.0, 0.0: 1.0}
