@@ -171,6 +171,7 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
 
 /* tuning/debug switches (not for production use): key 0 = force the generic GEMM kernel (0/1) */
 int inr_debug_set(int key, int value);
+int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds) */
 
 /* diagnostic: s[i] = sin(x[i]), c[i] = cos(x[i]) with the device routine used in the epilogues */
 int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream);

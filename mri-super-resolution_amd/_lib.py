@@ -77,6 +77,7 @@ SIGNATURES = {
     "inr_prof_reset": (C.c_int, []),
     "inr_prof_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),
     "inr_debug_set": (C.c_int, [C.c_int, C.c_int]),
+    "inr_debug_set_ptr": (C.c_int, [C.c_int, C.c_void_p]),
     "inr_sincos_probe": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_stream]),
 }
 

@@ -91,6 +91,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
 int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st);
 extern int g_force_generic;
+extern unsigned long long* g_stamps;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
 static const int64_t MAX_ROWS = (1ll << 31) - 256;
@@ -563,6 +564,11 @@ int inr_prof_read(int kernel_class, int64_t* launches, double* total_ms) {
     *launches = (int64_t)g_prof.spans[kernel_class].size();
     *total_ms = ms;
     return 0;
+}
+
+int inr_debug_set_ptr(int key, void* ptr) {
+    if (key == 0) { g_stamps = (unsigned long long*)ptr; return 0; }
+    return INR_E_INVALID;
 }
 
 int inr_debug_set(int key, int value) {

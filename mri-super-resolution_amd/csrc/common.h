@@ -63,71 +63,39 @@ struct ProfScope {
 };
 
 // ---- device math ---------------------------------------------------------------------------------
-// sin and cos of the same fp32 argument, <= 1.6 ulp each for |x| < 65536 (3-term fma Cody-Waite
-// reduction by pi/2 + minimax polynomials on [-pi/4, pi/4]); larger arguments take the libm path.
+// sin and cos of one fp32 argument.  On gfx950 the f32 MFMA and the f32 VALU share the same lanes (measured:
+// a wave's VALU epilogue does not overlap the co-resident wave's v_mfma_f32_32x32x2_f32 stream), so every VALU
+// instruction in a GEMM epilogue costs matrix time.  The argument is therefore reduced to a FRACTION OF A
+// REVOLUTION with two FMAs -- f = x/(2*pi) - rint(x/(2*pi)), |f| <= 0.5, single rounding of the exact
+// difference plus the 1/(2*pi) tail -- and handed to the transcendental unit (v_sin_f32 / v_cos_f32 take
+// revolutions).  6 instructions per element instead of ~24; measured abs error <= 3e-7 for |x| < 2^20
+// (hardware sin/cos: 1.4e-7 on [-0.5, 0.5] rev; argument: <= 3e-8 rev).  Larger arguments take the libm path.
+#define INR_INV_2PI_HI 1.59154936671257019e-01f
+#define INR_INV_2PI_LO 6.42063824329852650e-09f
+#define INR_SINCOS_FAST_LIMIT 1048576.0f
+
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
-    if (__builtin_expect(!(fabsf(x) < 65536.0f), 0)) {
+    if (__builtin_expect(!(fabsf(x) < INR_SINCOS_FAST_LIMIT), 0)) {
         sincosf(x, &s, &c);
         return;
     }
-    const float kf = rintf(x * 0.636619772367581343f);
-    float r = fmaf(-kf, 1.57079637050628662109e+00f, x);
-    r = fmaf(-kf, -4.37113882867379288655e-08f, r);
-    r = fmaf(-kf, -1.71512451000588187280e-15f, r);
-    const float u = r * r;
-    float ps = fmaf(2.7181986297364347e-06f, u, -0.00019839320157188922f);
-    ps = fmaf(ps, u, 0.008333329111337662f);
-    ps = fmaf(ps, u, -0.1666666716337204f);
-    const float sr = fmaf(r * u, ps, r);
-    float pc = fmaf(-2.7208204755879706e-07f, u, 2.479949216649402e-05f);
-    pc = fmaf(pc, u, -0.0013888883404433727f);
-    pc = fmaf(pc, u, 0.0416666679084301f);
-    const float cr = fmaf(u * u, pc, fmaf(-0.5f, u, 1.0f));
-    const int q = static_cast<int>(kf) & 3;
-    const float s0 = (q & 1) ? cr : sr;
-    const float c0 = (q & 1) ? sr : cr;
-    s = (q & 2) ? -s0 : s0;
-    c = ((q + 1) & 2) ? -c0 : c0;
+    const float k = rintf(x * INR_INV_2PI_HI);
+    float f = fmaf(x, INR_INV_2PI_HI, -k);
+    f = fmaf(x, INR_INV_2PI_LO, f);
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
 }
 
-// Two-at-a-time form of sincos_f32 for the GEMM epilogues: the reduction and both polynomials are written
-// on float2 so hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (half the VALU instructions); quadrant fix-up by
-// sign-bit xor.  Same constants and operation order per element as sincos_f32 => identical results.
+// Branch-free core of sincos_f32 on float2 (valid for |x| < INR_SINCOS_FAST_LIMIT; callers check that once per
+// tile and redo the tile through sincos_f32 otherwise, so the unrolled epilogue carries no libm code).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void sincos_f32x2(f32x2_t x, f32x2_t& s, f32x2_t& c) {
-    if (__builtin_expect(!(fabsf(x[0]) < 65536.0f && fabsf(x[1]) < 65536.0f), 0)) {
-        float s0, c0, s1, c1;
-        sincos_f32(x[0], s0, c0);
-        sincos_f32(x[1], s1, c1);
-        s = f32x2_t{s0, s1};
-        c = f32x2_t{c0, c1};
-        return;
-    }
-    const f32x2_t t = x * 0.636619772367581343f;
-    f32x2_t kf;
-    kf[0] = rintf(t[0]);
-    kf[1] = rintf(t[1]);
-    const f32x2_t nk = -kf;
-    f32x2_t r = __builtin_elementwise_fma(nk, (f32x2_t)(1.57079637050628662109e+00f), x);
-    r = __builtin_elementwise_fma(nk, (f32x2_t)(-4.37113882867379288655e-08f), r);
-    r = __builtin_elementwise_fma(nk, (f32x2_t)(-1.71512451000588187280e-15f), r);
-    const f32x2_t u = r * r;
-    f32x2_t ps = __builtin_elementwise_fma((f32x2_t)(2.7181986297364347e-06f), u, (f32x2_t)(-0.00019839320157188922f));
-    ps = __builtin_elementwise_fma(ps, u, (f32x2_t)(0.008333329111337662f));
-    ps = __builtin_elementwise_fma(ps, u, (f32x2_t)(-0.1666666716337204f));
-    const f32x2_t sr = __builtin_elementwise_fma(r * u, ps, r);
-    f32x2_t pc = __builtin_elementwise_fma((f32x2_t)(-2.7208204755879706e-07f), u, (f32x2_t)(2.479949216649402e-05f));
-    pc = __builtin_elementwise_fma(pc, u, (f32x2_t)(-0.0013888883404433727f));
-    pc = __builtin_elementwise_fma(pc, u, (f32x2_t)(0.0416666679084301f));
-    const f32x2_t cr = __builtin_elementwise_fma(u * u, pc, __builtin_elementwise_fma((f32x2_t)(-0.5f), u, (f32x2_t)(1.0f)));
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const unsigned q = static_cast<unsigned>(static_cast<int>(kf[e]));
-        const float s0 = (q & 1u) ? cr[e] : sr[e];
-        const float c0 = (q & 1u) ? sr[e] : cr[e];
-        s[e] = __uint_as_float(__float_as_uint(s0) ^ ((q & 2u) << 30));
-        c[e] = __uint_as_float(__float_as_uint(c0) ^ (((q + 1u) & 2u) << 30));
-    }
+__device__ __forceinline__ void sincos_f32x2_fast(f32x2_t x, f32x2_t& s, f32x2_t& c) {
+    const f32x2_t t = x * INR_INV_2PI_HI;
+    const f32x2_t k = f32x2_t{rintf(t[0]), rintf(t[1])};
+    f32x2_t f = __builtin_elementwise_fma(x, (f32x2_t)(INR_INV_2PI_HI), -k);
+    f = __builtin_elementwise_fma(x, (f32x2_t)(INR_INV_2PI_LO), f);
+    s = f32x2_t{__builtin_amdgcn_sinf(f[0]), __builtin_amdgcn_sinf(f[1])};
+    c = f32x2_t{__builtin_amdgcn_cosf(f[0]), __builtin_amdgcn_cosf(f[1])};
 }
 
 // bit-exact torch.linspace(-1, 1, n)[i] in fp32 (oracle/inr_oracle.py: linspace_pm1)

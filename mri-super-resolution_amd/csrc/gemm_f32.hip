@@ -20,8 +20,13 @@
 //       ahead into a second register set, the next tile's global loads / LDS stores are interleaved
 //       between the MFMAs with sched_group_barrier, and the single barrier per K-step sits between the
 //       third and fourth k block so the MFMAs that follow it already have their operands in registers.
-//       (Two co-resident blocks of a CU run in lockstep; whatever a wave does outside its MFMA stream
-//       leaves the matrix pipe idle for both, so that part is squeezed to the barrier itself.)
+//       Measured facts that shaped it (s_memtime stamps, tools/stamp_timeline.py; tools/mfma_rate.hip):
+//       the f32 MFMA shares the f32 VALU lanes -- a co-resident wave's VALU instructions issue about one
+//       per MFMA boundary, so an epilogue that overlaps the other block's main loop is stretched ~4x and
+//       every VALU instruction removed from it counts (hence v_sin/v_cos on an FMA-reduced argument and
+//       16-byte staged stores); a bare register-only 32x32x2 loop reaches 138-142 TFLOP/s on this part,
+//       which is the practical ceiling of the main loop (param-grad runs at 140-142).
+//       Start-time staggering of co-resident blocks and s_setprio in either direction were tried: no effect.
 //   gemm_f32_kernel       -- generic fallback (any shape/alignment: scalar guarded loads), same numerics.
 #include "common.h"
 
@@ -53,6 +58,7 @@ struct GemmParams {
     long long slab_stride;  // floats between consecutive split slabs of C
     int tiles_m, tiles_n;
     long long a_elems, b_elems, c_elems;  // total element counts of A, B, C (SRD bounds of the fast path)
+    unsigned long long* stamps;  // diagnostic builds (-DINR_STAMPS): 6 x u64 per wave
 };
 
 template <bool KC>
@@ -309,6 +315,19 @@ __device__ __forceinline__ void sched_interleave() {
     }
 }
 
+#ifdef INR_STAMPS
+#define INR_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (p.stamps && (threadIdx.x & 63) == 0) {                                                   \
+            unsigned long long t_;                                                                   \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+            p.stamps[((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = t_;            \
+        }                                                                                            \
+    } while (0)
+#else
+#define INR_STAMP(slot)
+#endif
+
 // NOTE: the row offset is folded into the VGPR offset and soffset stays the constant 0.  With an SGPR soffset
 // a 16-byte buffer store reads its data registers late, and on gfx950/ROCm 7.2 hipcc let the next VALU
 // instruction overwrite them (observed: lanes 12-15 of every 16 stored the FOLLOWING store's second dword).
@@ -355,6 +374,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 sub[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + l32] = acc[i][j][r];
+    INR_STAMP(5);
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
         const int col = n0 + wn * 64 + (lane & 15) * 4;
@@ -362,15 +382,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
     }
     const float* rd = sub + (lane >> 4) * 64 + (lane & 15) * 4;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    float zmax = 0.f;   // largest |omega*z| seen by this lane (sine epilogues)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
         const int so = q * a.row_step;
+        if (q == 8) INR_STAMP(6);
         if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
             const f32x4 z = p.omega * (v + bias);
+            zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(z[0]), fabsf(z[1]))), fmaxf(fabsf(z[2]), fabsf(z[3])));
             f32x2_t s01, c01, s23, c23;
-            sincos_f32x2(f32x2_t{z[0], z[1]}, s01, c01);
-            sincos_f32x2(f32x2_t{z[2], z[3]}, s23, c23);
+            sincos_f32x2_fast(f32x2_t{z[0], z[1]}, s01, c01);
+            sincos_f32x2_fast(f32x2_t{z[2], z[3]}, s23, c23);
             buf_store4(f32x4{s01[0], s01[1], s23[0], s23[1]}, a.srdC, a.voff, so);
             if (EPI == EPI_SINE_STASH)
                 buf_store4(p.omega * f32x4{c01[0], c01[1], c23[0], c23[1]}, a.srdC2, a.voff, so);
@@ -380,6 +403,26 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
             buf_store4(o, a.srdC, a.voff, so);
         } else {
             buf_store4(v, a.srdC, a.voff, so);
+        }
+    }
+    if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
+        // rare: an argument beyond the fast range (or NaN) somewhere in the wave's tile -> redo it through libm
+        if (__builtin_expect(__any(!(zmax < INR_SINCOS_FAST_LIMIT)), 0)) {
+#pragma unroll 1
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
+                const f32x4 z = p.omega * (v + bias);
+                f32x4 sv, cv;
+#pragma unroll 1
+                for (int e = 0; e < 4; ++e) {
+                    float s1, c1;
+                    sincos_f32(z[e], s1, c1);
+                    sv[e] = s1;
+                    cv[e] = c1;
+                }
+                buf_store4(sv, a.srdC, a.voff, q * a.row_step);
+                if (EPI == EPI_SINE_STASH) buf_store4(p.omega * cv, a.srdC2, a.voff, q * a.row_step);
+            }
         }
     }
     if (EPI == EPI_MUL && p.colsum) {
@@ -411,7 +454,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
     const int k_begin = tc.split * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const int ktiles = (k_end - k_begin + BK - 1) / BK;
-
+#ifdef INR_STAMPS
+    if (p.stamps && lane == 0)
+        p.stamps[((long long)blockIdx.x * 4 + wave) * 8 + 7] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20) << 32) |
+            __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+#endif
+    INR_STAMP(0);
     // block-local SRDs: base at the tile's first element, extent to the end of the operand
     const long long a_first = A_KC ? ((long long)m0 * p.lda + k_begin) : ((long long)k_begin * p.lda + m0);
     const long long b_first = B_KC ? ((long long)n0 * p.ldb + k_begin) : ((long long)k_begin * p.ldb + n0);
@@ -449,6 +498,10 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
     __syncthreads();
     if (ktiles > 0) read_frags<A_KC, B_KC>(f0, smem, smem + BOFF, arow, brow, 0, h);
 
+    // Issue priority: a wave in its MFMA stream outranks a co-resident wave that is in its (VALU-dense)
+    // epilogue.  Arbitration is priority-then-age; without this an OLDER wave's epilogue starves the younger
+    // wave's MFMA issue and the matrix pipe idles for the length of every epilogue.
+    INR_STAMP(1);
     int a_off = 0, b_off = 0;
     for (int t = 0; t + 1 < ktiles; ++t) {
         const float* cA = smem + (t & 1) * STAGE;
@@ -509,15 +562,20 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
         mfma_block(acc, f1);
     }
 
+    INR_STAMP(2);
     __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue staging area
+    INR_STAMP(3);
     epilogue_staged<EPI>(p, acc, smem + wave * 4096, ea, mulreg, n0, wn, lane, tc.tile_m * 2 + wm);
+    INR_STAMP(4);
 }
 
+unsigned long long* g_stamps = nullptr;  // diagnostic builds only
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
 
 // ---- host-side launch --------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fast = nullptr) {
+    p.stamps = g_stamps;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const long long total = (long long)p.tiles_m * p.tiles_n * p.splits;

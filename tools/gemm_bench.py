@@ -1,5 +1,5 @@
 import sys, os, ctypes, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mri_super_resolution_amd as inr
 from mri_super_resolution_amd import ops, _lib
 N=524288; H=512
@@ -19,4 +19,4 @@ for stag in [int(a) for a in sys.argv[1:]] or [0]:
     t1=timeit(lambda: ops.sine_layer_forward(x,W,b,30.0,True))
     t2=timeit(lambda: ops.sine_layer_backward_input(dz,W,dact))
     t3=timeit(lambda: ops.linear_param_grad(dz,x,False))
-    print(f"stagger={stag}: fwd {t1:.3f} ms {fl/t1:.1f} TF | dX {t2:.3f} ms {fl/t2:.1f} TF | dW {t3:.3f} ms {fl/t3:.1f} TF", flush=True)
+    print(f"generic={stag}: fwd {t1:.3f} ms {fl/t1:.1f} TF | dX {t2:.3f} ms {fl/t2:.1f} TF | dW {t3:.3f} ms {fl/t3:.1f} TF", flush=True)
