@@ -162,10 +162,24 @@ def main():
         tot_flop += flop
         tot_launch += launches
     other_launches, other_ms = ops.prof_read(3)
+    # HBM traffic of the GEMM kernel per launch: PMC counters cannot be read from inside this process, so the
+    # committed rocprofv3 summary of this same command is used (profiles/r01_pmc_hbm.json: FETCH_SIZE x2 per
+    # the gfx950 correction + WRITE_SIZE, separate --pmc passes); null when the summary is absent.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as fh:
+            traffic = json.load(fh).get("gemm_f32_avg_hbm_bytes_per_launch")
+        traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same command)"
+    # algorithmic HBM bytes of the 11 GEMM launches of one step, in units of one [N,512] fp32 matrix:
+    # forward 0.5+2 (layer 0) + 3*(1+2); input-grad 3*(1+1+1); param-grad 1.5 (layer 0) + 3*2  = 28 matrices
+    algo_bytes = 28.0 * n_lr * HIDDEN * 4 / 11.0
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+    roofline = {"bound": "mfma", "kernel": "gemm_f32_pipe_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "launches": tot_launch, "avg_launch_ms": tot_ms / max(tot_launch, 1),
+                "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "launches": tot_launch, "avg_launch_ms": tot_ms / max(tot_launch, 1),
                 "gemm_ms_per_step": tot_ms / args.steps, "other_kernels_ms_per_step": other_ms / args.steps,
                 "per_class": classes}
     ops.prof_reset()
