@@ -162,6 +162,24 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
                   int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps,
                   float* losses, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a-12: end-of-fit metrics on the device (fp64 accumulation, fixed-order reductions) -----------------
+ * workspace for all three image metrics: inr_metric_workspace_bytes(n_images).
+ * inr_psnr:   out[b] (double) = 10*log10(data_range^2 / mean((x_b - y_b)^2)); x, y are [n_images][per_image] fp32.
+ *             (the definition of skimage.metrics.peak_signal_noise_ratio, imported at master.py:14)
+ * inr_ssim2d: out[b] (double) = skimage-0.20 structural_similarity(x_b, y_b, data_range) with default arguments
+ *             (uniform win x win window, sample covariance, K1=.01, K2=.03, border crop) on [n_images][H][W] fp32;
+ *             use_mask != 0 multiplies both images by (x > mask_thr) first -- the protocol of
+ *             superresDWI.py:183-186.
+ * inr_adc_map: calculate_ADC (SRDWI.py:118-130): out[p] = clip(-slope of lstsq(log(data[p][:] + 1e-7) ~ b/1000), -10, 3)
+ *             for data [n_pixels][n_b] fp32, bvals [n_b] fp32 (n_b <= 32). */
+size_t inr_metric_workspace_bytes(int n_images);
+int inr_psnr(double* out, const float* x, const float* y, int n_images, int64_t per_image, double data_range,
+             void* workspace, size_t workspace_bytes, void* stream);
+int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int height, int width, int win,
+               double data_range, int use_mask, float mask_thr, void* workspace, size_t workspace_bytes,
+               void* stream);
+int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream);
+
 /* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
  * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */
 int  inr_prof_enable(int enable);

@@ -90,6 +90,12 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int
                 double b2, double eps, hipStream_t st);
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
 int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st);
+int metric_workspace_doubles(int nimg);
+int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t per_image, double data_range,
+                double* ws, hipStream_t st);
+int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
+                int use_mask, float mask_thr, double* ws, hipStream_t st);
+int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
 extern int g_force_generic;
 extern unsigned long long* g_stamps;
 
@@ -530,6 +536,41 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
         if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
     }
     return 0;
+}
+
+// ---- metrics ---------------------------------------------------------------------------------------------
+size_t inr_metric_workspace_bytes(int n_images) {
+    return (size_t)metric_workspace_doubles(n_images > 0 ? n_images : 1) * sizeof(double);
+}
+
+int inr_psnr(double* out, const float* x, const float* y, int n_images, int64_t per_image, double data_range,
+             void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(out && x && y, INR_E_INVALID, "inr_psnr: null pointer");
+    INR_REQUIRE(n_images >= 1 && n_images <= 65535 && per_image >= 1 && data_range > 0, INR_E_INVALID,
+                "inr_psnr: bad sizes");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_metric_workspace_bytes(n_images), INR_E_WORKSPACE,
+                "inr_psnr: workspace too small");
+    return launch_psnr(out, x, y, n_images, per_image, data_range, (double*)workspace, (hipStream_t)stream);
+}
+
+int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int height, int width, int win,
+               double data_range, int use_mask, float mask_thr, void* workspace, size_t workspace_bytes,
+               void* stream) {
+    INR_REQUIRE(out && x && y, INR_E_INVALID, "inr_ssim2d: null pointer");
+    INR_REQUIRE(n_images >= 1 && n_images <= 65535 && win >= 3 && (win & 1) && height >= win && width >= win &&
+                    data_range > 0,
+                INR_E_INVALID, "inr_ssim2d: need odd win >= 3 and images at least win x win (got %dx%d, win %d)",
+                height, width, win);
+    INR_REQUIRE(workspace && workspace_bytes >= inr_metric_workspace_bytes(n_images), INR_E_WORKSPACE,
+                "inr_ssim2d: workspace too small");
+    return launch_ssim(out, x, y, n_images, height, width, win, data_range, use_mask, mask_thr, (double*)workspace,
+                       (hipStream_t)stream);
+}
+
+int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream) {
+    INR_REQUIRE(out && data && bvals, INR_E_INVALID, "inr_adc_map: null pointer");
+    INR_REQUIRE(n_pixels >= 0 && n_b >= 2 && n_b <= 32, INR_E_INVALID, "inr_adc_map: need 2 <= n_b <= 32");
+    return launch_adc(out, data, bvals, n_pixels, n_b, (hipStream_t)stream);
 }
 
 // ---- profiler --------------------------------------------------------------------------------------------

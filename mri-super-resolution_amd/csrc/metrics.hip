@@ -1,0 +1,164 @@
+// End-of-fit metrics on the device: PSNR, skimage-compatible SSIM, ADC maps.
+// The reference computes them on the host after copying the reconstruction back
+// (superresDWI.py:179-186 skimage structural_similarity; SRDWI.py:118-130 per-pixel np.polyfit in a Python
+// double loop).  Here the volume stays in HBM; everything accumulates in fp64 with fixed-order reductions.
+#include "common.h"
+
+namespace inr {
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double* red /*[4]*/) {
+    v = wave_sum_f64(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+
+// partial[b][blk] = sum over a slice of image b of (x - y)^2
+__global__ void __launch_bounds__(256) sqdiff_kernel(double* __restrict__ partial, const float* __restrict__ x,
+                                                     const float* __restrict__ y, int64_t per_image, int blocks_per_image) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * per_image;
+    const float* yb = y + (int64_t)b * per_image;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_image; i += (int64_t)blocks_per_image * 256) {
+        const double d = (double)xb[i] - (double)yb[i];
+        acc += d * d;
+    }
+    const double s = block_sum_f64(acc, red);
+    if (threadIdx.x == 0) partial[(int64_t)b * blocks_per_image + blockIdx.x] = s;
+}
+
+// out[b] = 10*log10(range^2 / (sum_k partial[b][k] / per_image))
+__global__ void psnr_finish_kernel(double* __restrict__ out, const double* __restrict__ partial, int blocks_per_image,
+                                   int64_t per_image, double data_range, int nimg) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nimg) return;
+    double s = 0.0;
+    for (int k = 0; k < blocks_per_image; ++k) s += partial[(int64_t)b * blocks_per_image + k];
+    const double mse = s / (double)per_image;
+    out[b] = 10.0 * log10(data_range * data_range / mse);
+}
+
+// skimage 0.20 structural_similarity(x, y, data_range=R) for 2-D float images with default arguments:
+// uniform win x win window (win = 7), sample covariance (N/(N-1)), K1 = 0.01, K2 = 0.03, mean of S over the image
+// cropped by (win-1)/2 on every side.  Optional masking as at superresDWI.py:183-186: both images are multiplied by
+// (x > mask_thr) when use_mask != 0.  One thread per cropped pixel; grid = (blocks, images).
+__global__ void __launch_bounds__(256) ssim_kernel(double* __restrict__ partial, const float* __restrict__ x,
+                                                   const float* __restrict__ y, int H, int W, int win, double c1,
+                                                   double c2, int use_mask, float mask_thr, int blocks_per_image) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * H * W;
+    const float* yb = y + (int64_t)b * H * W;
+    const int pad = (win - 1) / 2;
+    const int h = H - 2 * pad, w = W - 2 * pad;
+    const int64_t count = (int64_t)h * w;
+    const double np_ = (double)win * win, cov_norm = np_ / (np_ - 1.0);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)blocks_per_image * 256) {
+        const int r = (int)(i / w), c = (int)(i - (int64_t)r * w);
+        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dr = 0; dr < win; ++dr) {
+            const float* xr = xb + (int64_t)(r + dr) * W + c;
+            const float* yr = yb + (int64_t)(r + dr) * W + c;
+            for (int dc = 0; dc < win; ++dc) {
+                double xv = xr[dc], yv = yr[dc];
+                if (use_mask) {
+                    const double m = xr[dc] > mask_thr ? 1.0 : 0.0;
+                    xv *= m;
+                    yv *= m;
+                }
+                sx += xv; sy += yv; sxx += xv * xv; syy += yv * yv; sxy += xv * yv;
+            }
+        }
+        const double ux = sx / np_, uy = sy / np_;
+        const double vx = cov_norm * (sxx / np_ - ux * ux), vy = cov_norm * (syy / np_ - uy * uy);
+        const double vxy = cov_norm * (sxy / np_ - ux * uy);
+        acc += ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2));
+    }
+    const double s = block_sum_f64(acc, red);
+    if (threadIdx.x == 0) partial[(int64_t)b * blocks_per_image + blockIdx.x] = s;
+}
+
+__global__ void mean_finish_kernel(double* __restrict__ out, const double* __restrict__ partial, int blocks_per_image,
+                                   double count, int nimg) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nimg) return;
+    double s = 0.0;
+    for (int k = 0; k < blocks_per_image; ++k) s += partial[(int64_t)b * blocks_per_image + k];
+    out[b] = s / count;
+}
+
+// calculate_ADC (SRDWI.py:118-130): per pixel, -slope of the degree-1 least-squares fit of log(S + 1e-7) against
+// b/1000, clipped to [-10, 3]; closed form of np.polyfit.  data[npix][nb], bvals[nb] (nb <= 32).
+__global__ void __launch_bounds__(256) adc_kernel(float* __restrict__ out, const float* __restrict__ data,
+                                                  const float* __restrict__ bvals, int64_t npix, int nb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    double bm = 0.0;
+    for (int k = 0; k < nb; ++k) bm += (double)bvals[k] / 1000.0;
+    bm /= nb;
+    double ym = 0.0, yv[32];
+    for (int k = 0; k < nb; ++k) {
+        yv[k] = log((double)data[i * nb + k] + 1e-7);
+        ym += yv[k];
+    }
+    ym /= nb;
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const double db = (double)bvals[k] / 1000.0 - bm;
+        num += db * (yv[k] - ym);
+        den += db * db;
+    }
+    double adc = -(num / den);
+    adc = adc > 3.0 ? 3.0 : (adc < -10.0 ? -10.0 : adc);
+    out[i] = (float)adc;
+}
+
+constexpr int METRIC_BLOCKS = 64;
+
+int metric_workspace_doubles(int nimg) { return nimg * METRIC_BLOCKS; }
+
+int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t per_image, double data_range,
+                double* ws, hipStream_t st) {
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(sqdiff_kernel, dim3(METRIC_BLOCKS, nimg), dim3(256), 0, st, ws, x, y, per_image, METRIC_BLOCKS);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(psnr_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, ws, METRIC_BLOCKS, per_image,
+                       data_range, nimg);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
+                int use_mask, float mask_thr, double* ws, hipStream_t st) {
+    const int pad = (win - 1) / 2;
+    const double c1 = (0.01 * data_range) * (0.01 * data_range), c2 = (0.03 * data_range) * (0.03 * data_range);
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(ssim_kernel, dim3(METRIC_BLOCKS, nimg), dim3(256), 0, st, ws, x, y, H, W, win, c1, c2, use_mask,
+                       mask_thr, METRIC_BLOCKS);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, ws, METRIC_BLOCKS,
+                       (double)(H - 2 * pad) * (double)(W - 2 * pad), nimg);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st) {
+    if (npix == 0) return 0;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(adc_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, out, data, bvals, npix, nb);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace inr
