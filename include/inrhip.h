@@ -86,6 +86,17 @@ int inr_grid_fourier_map(float* out, const int64_t* shape, int dim, int64_t row_
 int inr_sine_layer_forward(float* act, float* dact, const float* x, const float* W, const float* b,
                            int64_t n, int in_features, int out_features, float omega, void* stream);
 
+/* ---- a-10: PerturbNet layers (SRDWI.py:93-109) ---------------------------------------------------------
+ * hidden layer:  act = scale*tanh(x W^T + b), dact (nullable) = scale*(1 - tanh^2)   [same GEMM as the sine layer]
+ * output layer:  y[n][out] = scale*tanh(a W^T + b) (scale = eps, SRDWI.py:107), dy (nullable) its derivative;
+ *                row-dot per output with a wavefront shuffle reduction (out = d = 2..4 columns).
+ * The constant acquisition column of SRDWI.py:102-104 is folded into the bias by the caller:
+ * b_eff = b + (sample/10) * W[:, in]  (so x stays the [n, in] feature matrix and nothing is concatenated). */
+int inr_tanh_layer_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
+                           int in_features, int out_features, float scale, void* stream);
+int inr_linear_tanh_head_forward(float* y, float* dy, const float* a, const float* W, const float* b, int64_t n,
+                                 int in_features, int out_features, float scale, void* stream);
+
 /* element-wise out = a*b over `count` floats: dz = grad_out * dact, the first step of a stand-alone
  * SineLayer's backward (what autograd does for torch.sin(omega*z), SRDWI.py:59).  out may alias a or b. */
 int inr_mul(float* out, const float* a, const float* b, int64_t count, void* stream);

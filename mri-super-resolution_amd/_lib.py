@@ -44,6 +44,10 @@ SIGNATURES = {
     "inr_grid_fourier_map": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int64, C.c_int64, c_f32p, C.c_int, c_stream]),
     "inr_sine_layer_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int,
                                          C.c_float, c_stream]),
+    "inr_tanh_layer_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_float, c_stream]),
+    "inr_linear_tanh_head_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int,
+                                               C.c_float, c_stream]),
     "inr_mul": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_stream]),
     "inr_linear_head_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                           C.c_float, c_stream]),

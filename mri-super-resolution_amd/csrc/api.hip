@@ -71,7 +71,9 @@ int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, i
 int launch_fourier(float* out, const float* x, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
                    const float* B, int m, hipStream_t st);
 int launch_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n, int hidden,
-                        int out_f, int use_clamp, float clamp_min, hipStream_t st);
+                        int out_f, int use_clamp, float clamp_min, hipStream_t st, float* dy = nullptr);
+int gemm_tanh_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n, int in_f,
+                      int out_f, float scale, hipStream_t stream);
 int mse_blocks(int64_t count);
 int launch_mse(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
                float* partial, hipStream_t st);
@@ -265,6 +267,22 @@ int inr_sine_layer_forward(float* act, float* dact, const float* x, const float*
                 "inr_sine_layer_forward: bad sizes n=%lld in=%d out=%d", (long long)n, in_features, out_features);
     if (n == 0) return 0;
     return gemm_sine_forward(act, dact, x, W, b, n, in_features, out_features, omega, (hipStream_t)stream);
+}
+
+int inr_tanh_layer_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
+                           int in_features, int out_features, float scale, void* stream) {
+    INR_REQUIRE(act && x && W, INR_E_INVALID, "inr_tanh_layer_forward: null pointer");
+    INR_REQUIRE(n >= 0 && n <= MAX_ROWS && in_features >= 1 && out_features >= 1, INR_E_INVALID,
+                "inr_tanh_layer_forward: bad sizes");
+    if (n == 0) return 0;
+    return gemm_tanh_forward(act, dact, x, W, b, n, in_features, out_features, scale, (hipStream_t)stream);
+}
+
+int inr_linear_tanh_head_forward(float* y, float* dy, const float* a, const float* W, const float* b, int64_t n,
+                                 int in_features, int out_features, float scale, void* stream) {
+    INR_REQUIRE(y && a && W, INR_E_INVALID, "inr_linear_tanh_head_forward: null pointer");
+    INR_REQUIRE(n >= 0 && in_features >= 1 && out_features >= 1, INR_E_INVALID, "inr_linear_tanh_head_forward: bad sizes");
+    return launch_head_forward(y, a, W, b, n, in_features, out_features, 2, scale, (hipStream_t)stream, dy);
 }
 
 int inr_mul(float* out, const float* a, const float* b, int64_t count, void* stream) {

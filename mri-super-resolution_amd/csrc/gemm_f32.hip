@@ -40,7 +40,8 @@ constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
 constexpr int LDK = BK + 4;  // k-contiguous LDS row stride (floats)
 constexpr int LDM = BM;      // m-contiguous LDS row stride (floats)
 
-enum Epilogue { EPI_SINE = 0, EPI_SINE_STASH = 1, EPI_MUL = 2, EPI_PLAIN = 3 };
+enum Epilogue { EPI_SINE = 0, EPI_SINE_STASH = 1, EPI_MUL = 2, EPI_PLAIN = 3, EPI_TANH = 4, EPI_TANH_STASH = 5 };
+// EPI_TANH*: act = omega*tanh(acc + bias), stash = omega*(1 - tanh^2)   (PerturbNet layers, SRDWI.py:103-107; `omega` = scale)
 
 struct GemmParams {
     const float* A;
@@ -155,7 +156,8 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc
         const int col = n0 + wn * 64 + j * 32 + l32;
         if (CHECK && col >= p.N) continue;
         float bias = 0.f;
-        if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) bias = p.bias ? p.bias[col] : 0.f;
+        if (EPI == EPI_SINE || EPI == EPI_SINE_STASH || EPI == EPI_TANH || EPI == EPI_TANH_STASH)
+            bias = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row_base = m0 + wm * 64 + i * 32 + 4 * h;
@@ -171,6 +173,10 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc
                     sincos_f32(p.omega * (v + bias), s, c);
                     C[off] = s;
                     if (EPI == EPI_SINE_STASH) p.C2[off] = p.omega * c;
+                } else if (EPI == EPI_TANH || EPI == EPI_TANH_STASH) {
+                    const float t = tanhf(v + bias);
+                    C[off] = p.omega * t;
+                    if (EPI == EPI_TANH_STASH) p.C2[off] = p.omega * (1.0f - t * t);
                 } else if (EPI == EPI_MUL) {
                     C[off] = v * p.mul[off];
                 } else {
@@ -353,7 +359,8 @@ __device__ __forceinline__ EpiAddr epi_addr(const GemmParams& p, int m0, int n0,
     const long long c_end = (p.splits > 1 || p.slab_stride) ? (long long)(split + 1) * p.slab_stride : p.c_elems;
     const long long bytes = min(c_end - first, (long long)BM * p.ldc) * 4;   // this block's 128-row window only
     a.srdC = make_srd(p.C + first, bytes);
-    a.srdC2 = make_srd(EPI == EPI_SINE_STASH ? p.C2 + first : p.C, EPI == EPI_SINE_STASH ? bytes : 0);
+    constexpr bool STASH = (EPI == EPI_SINE_STASH || EPI == EPI_TANH_STASH);
+    a.srdC2 = make_srd(STASH ? p.C2 + first : p.C, STASH ? bytes : 0);
     a.srdMul = make_srd(EPI == EPI_MUL ? p.mul + first : p.A, EPI == EPI_MUL ? bytes : 0);
     const int row = wm * 64 + (lane >> 4), col = wn * 64 + (lane & 15) * 4;
     // a lane whose columns fall outside N is pushed out of the SRD range: its loads read 0, its stores drop
@@ -376,7 +383,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
                 sub[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + l32] = acc[i][j][r];
     INR_STAMP(5);
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
+    if (EPI == EPI_SINE || EPI == EPI_SINE_STASH || EPI == EPI_TANH || EPI == EPI_TANH_STASH) {
         const int col = n0 + wn * 64 + (lane & 15) * 4;
         if (p.bias && col < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
     }
@@ -397,6 +404,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
             buf_store4(f32x4{s01[0], s01[1], s23[0], s23[1]}, a.srdC, a.voff, so);
             if (EPI == EPI_SINE_STASH)
                 buf_store4(p.omega * f32x4{c01[0], c01[1], c23[0], c23[1]}, a.srdC2, a.voff, so);
+        } else if (EPI == EPI_TANH || EPI == EPI_TANH_STASH) {
+            const f32x4 z = v + bias;
+            const f32x4 t = f32x4{tanhf(z[0]), tanhf(z[1]), tanhf(z[2]), tanhf(z[3])};
+            buf_store4(p.omega * t, a.srdC, a.voff, so);
+            if (EPI == EPI_TANH_STASH) buf_store4(p.omega * (1.0f - t * t), a.srdC2, a.voff, so);
         } else if (EPI == EPI_MUL) {
             const f32x4 o = v * mulreg[q];   // rows past M: v == 0 and mulreg == 0, so they add nothing below
             csum += o;
@@ -619,6 +631,24 @@ int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, c
     ProfScope ps(KC_GEMM_FWD, stream);
     if (dact) return launch_gemm<true, true, EPI_SINE_STASH>(p, vec, stream);
     return launch_gemm<true, true, EPI_SINE>(p, vec, stream);
+}
+
+// act[n][out] = scale*tanh(x W^T + b), optional dact = scale*(1 - tanh^2)   (PerturbNet hidden layer)
+int gemm_tanh_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n, int in_f,
+                      int out_f, float scale, hipStream_t stream) {
+    GemmParams p{};
+    p.A = x; p.B = W; p.C = act; p.C2 = dact; p.bias = b; p.mul = nullptr;
+    p.M = (int)n; p.N = out_f; p.K = in_f;
+    p.lda = in_f; p.ldb = in_f; p.ldc = out_f;
+    p.omega = scale;
+    p.splits = 1;
+    p.k_per_split = (in_f + BK - 1) / BK * BK;
+    p.slab_stride = 0;
+    p.a_elems = (long long)n * in_f; p.b_elems = (long long)out_f * in_f; p.c_elems = (long long)n * out_f;
+    const bool vec = vec_ok(x, W, in_f, in_f, in_f, in_f);
+    ProfScope ps(KC_OTHER, stream);
+    if (dact) return launch_gemm<true, true, EPI_TANH_STASH>(p, vec, stream);
+    return launch_gemm<true, true, EPI_TANH>(p, vec, stream);
 }
 
 // dz_prev[n][in] = (dz[n][out] @ W[out][in]) * mul[n][in]   (mul nullable)

@@ -74,7 +74,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(256) head_forward_kernel(float* __restrict__ y, const float* __restrict__ a,
+__global__ void __launch_bounds__(256) head_forward_kernel(float* __restrict__ y, float* __restrict__ dy,
+                                                           const float* __restrict__ a,
                                                            const float* __restrict__ W,
                                                            const float* __restrict__ b, int64_t n, int hidden,
                                                            int out_f, int use_clamp, float clamp_min) {
@@ -101,7 +102,12 @@ __global__ void __launch_bounds__(256) head_forward_kernel(float* __restrict__ y
             acc = wave_sum(acc);
             if (lane == 0) {
                 float v = acc + (b ? b[o] : 0.f);
-                if (use_clamp) v = fmaxf(v, clamp_min);
+                if (use_clamp == 1) v = fmaxf(v, clamp_min);
+                if (use_clamp == 2) {   // PerturbNet output: clamp_min carries the scale eps (SRDWI.py:107)
+                    const float t = tanhf(v);
+                    v = clamp_min * t;
+                    if (dy) dy[row * out_f + o] = clamp_min * (1.0f - t * t);
+                }
                 y[row * out_f + o] = v;
             }
         }
@@ -333,17 +339,18 @@ int launch_fourier(float* out, const float* x, const int64_t* shape, int dim, in
     return 0;
 }
 
+// mode (use_clamp): 0 plain, 1 clamp(min=clamp_min), 2 y = clamp_min*tanh(.) with optional derivative dy
 int launch_head_forward(float* y, const float* a, const float* W, const float* b, int64_t n, int hidden,
-                        int out_f, int use_clamp, float clamp_min, hipStream_t st) {
+                        int out_f, int use_clamp, float clamp_min, hipStream_t st, float* dy = nullptr) {
     if (n == 0) return 0;
     const bool vec = aligned16(a) && aligned16(W) && (hidden % 4 == 0);
     ProfScope ps(KC_OTHER, st);
     const dim3 grid(blocks_for(n, 4, 256 * 32));
     if (vec)
-        hipLaunchKernelGGL(head_forward_kernel<true>, grid, dim3(256), 0, st, y, a, W, b, n, hidden, out_f,
+        hipLaunchKernelGGL(head_forward_kernel<true>, grid, dim3(256), 0, st, y, dy, a, W, b, n, hidden, out_f,
                            use_clamp, clamp_min);
     else
-        hipLaunchKernelGGL(head_forward_kernel<false>, grid, dim3(256), 0, st, y, a, W, b, n, hidden, out_f,
+        hipLaunchKernelGGL(head_forward_kernel<false>, grid, dim3(256), 0, st, y, dy, a, W, b, n, hidden, out_f,
                            use_clamp, clamp_min);
     INR_LAUNCH_CHECK();
     return 0;

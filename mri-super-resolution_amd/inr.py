@@ -387,12 +387,40 @@ def reconstruct(model: Siren, shape, B=None, clamp_min=0.0, chunk_rows=1 << 20):
 
 
 # ---------------------------------------------------------------------------------------------------
-# a-10 PerturbNet (adjacent path; HIP kernels for it are a "next" row -- SURVEY.md 8(f)-2)
+# a-10 PerturbNet
 # ---------------------------------------------------------------------------------------------------
+class _PNFn(torch.autograd.Function):
+    """PerturbNet forward/backward on the HIP kernels: tanh hidden layer = the fp32-MFMA GEMM with a tanh
+    epilogue, output layer = shuffle-reduced row dots with eps*tanh; the constant acquisition column
+    (SRDWI.py:102-104) is folded into the hidden bias instead of concatenating an [N, F+1] matrix."""
+
+    @staticmethod
+    def forward(ctx, x, acq, eps, w1, b1, w2, b2):
+        stash = any(ctx.needs_input_grad[3:])
+        fin = x.shape[1]
+        w1a = w1[:, :fin].contiguous()
+        b_eff = (b1 + acq * w1[:, fin]).contiguous()
+        hid, dhid = ops.tanh_layer_forward(x.contiguous(), w1a, b_eff, 1.0, stash)
+        out, dout = ops.linear_tanh_head_forward(hid, w2.contiguous(), b2, eps, stash)
+        if stash:
+            ctx.acq = acq
+            ctx.save_for_backward(x, hid, dhid, dout, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, hid, dhid, dout, w2 = ctx.saved_tensors
+        dz2 = ops.mul(g.contiguous(), dout)
+        dz1, gw2, gb2, gb1 = ops.linear_head_backward(dz2, hid, dhid, w2.contiguous(), need_dz=True, need_param=True,
+                                                      need_bias_last=True)
+        gw1a, _ = ops.linear_param_grad(dz1, x, need_bias=False)
+        gw1 = torch.cat([gw1a, (ctx.acq * gb1).unsqueeze(1)], dim=1)
+        return None, None, None, gw1, gb1, gw2, gb2
+
+
 class PN(nn.Module):
-    """SRDWI.py:93-109 (``dimension`` outputs) / nn_mri.py:148-164 (fixed 2 outputs when ``dimension``
-    is omitted).  Runs as stock device ops for now: the tanh-MLP kernels are scheduled after the INR
-    path (out of scope this round)."""
+    """SRDWI.py:93-109 (``dimension`` outputs) / nn_mri.py:148-164 (2 outputs when ``dimension`` is omitted):
+    ``eps * tanh(Linear2(tanh(Linear1(cat(coords, sample/10)))))`` with the input detached (SRDWI.py:101)."""
 
     def __init__(self, in_features, hidden_features, dimension=2):
         super().__init__()
@@ -401,10 +429,10 @@ class PN(nn.Module):
         self.perturb_linear2 = nn.Linear(hidden_features, dimension)
 
     def forward(self, coords, sample=0, eps=0):
-        coords = coords.clone().detach().requires_grad_(False)
-        acq = torch.tensor([sample / 10.], dtype=torch.float, device=coords.device).repeat(coords.size(0), 1)
-        hidden = self.tanh(self.perturb_linear(torch.cat((coords, acq), -1)))
-        return eps * self.tanh(self.perturb_linear2(hidden))
+        coords = coords.detach()
+        acq = float(np.float32(sample / 10.))      # torch.tensor([sample/10.], dtype=torch.float) in the reference
+        return _PNFn.apply(coords.reshape(-1, coords.shape[-1]), acq, float(eps), self.perturb_linear.weight,
+                           self.perturb_linear.bias, self.perturb_linear2.weight, self.perturb_linear2.bias)
 
 
 # ---------------------------------------------------------------------------------------------------

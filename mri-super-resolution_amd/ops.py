@@ -133,6 +133,40 @@ def sine_layer_forward(x, W, b, omega: float, stash: bool):
     return act, dact
 
 
+def tanh_layer_forward(x, W, b, scale: float, stash: bool):
+    """act = scale*tanh(x W^T + b) and (if ``stash``) its derivative factor scale*(1-tanh^2)."""
+    _chk(x, "x")
+    _chk(W, "weight")
+    if x.dim() != 2 or W.dim() != 2 or x.shape[1] != W.shape[1]:
+        raise ValueError(f"x {tuple(x.shape)} / weight {tuple(W.shape)} mismatch")
+    n, fin = x.shape
+    fout = W.shape[0]
+    if b is not None:
+        _chk(b, "bias", (fout,))
+    act = torch.empty((n, fout), dtype=torch.float32, device=x.device)
+    dact = torch.empty_like(act) if stash else None
+    check(lib().inr_tanh_layer_forward(act.data_ptr(), _ptr(dact), x.data_ptr(), W.data_ptr(), _ptr(b), n, fin, fout,
+                                       float(scale), _stream()), "inr_tanh_layer_forward")
+    return act, dact
+
+
+def linear_tanh_head_forward(a, W, b, scale: float, stash: bool):
+    """y = scale*tanh(a W^T + b) for a few output columns, and (if ``stash``) scale*(1-tanh^2)."""
+    _chk(a, "a")
+    _chk(W, "weight")
+    if a.dim() != 2 or W.dim() != 2 or a.shape[1] != W.shape[1]:
+        raise ValueError(f"a {tuple(a.shape)} / weight {tuple(W.shape)} mismatch")
+    n, hidden = a.shape
+    out_f = W.shape[0]
+    if b is not None:
+        _chk(b, "bias", (out_f,))
+    y = torch.empty((n, out_f), dtype=torch.float32, device=a.device)
+    dy = torch.empty_like(y) if stash else None
+    check(lib().inr_linear_tanh_head_forward(y.data_ptr(), _ptr(dy), a.data_ptr(), W.data_ptr(), _ptr(b), n, hidden,
+                                             out_f, float(scale), _stream()), "inr_linear_tanh_head_forward")
+    return y, dy
+
+
 def mul(a, b):
     _chk(a, "a")
     _chk(b, "b", a.shape)

@@ -417,3 +417,61 @@ def test_full_size_synthetic128_properties():
     assert O.rel_l2(host(gb1 + gb2), host(gb)) < 1e-5
     ref_gb = dz.double().sum(0)
     assert O.rel_l2(host(gb), host(ref_gb)) < 1e-5
+
+
+# ------------------------------------------------------------------ a-10 PerturbNet --------------------------------
+def test_pn_forward_matches_reference(golden):
+    p = golden("pn.npz")
+    torch.manual_seed(0)
+    pn = inr.PN(256, 128, 3)
+    for n, q in pn.named_parameters():
+        assert np.array_equal(bits(q.detach().numpy()), bits(p[f"param/{n}"])), n      # same init draws as SRDWI.PN
+    pn.cuda()
+    x = dev(p["in"])
+    with torch.no_grad():
+        assert O.rel_l2(host(pn(x, 3, 1 / 128.)), p["out_s3"]) < T1
+        assert O.rel_l2(host(pn(x, 0, 1 / 128.)), p["out_s0"]) < T1
+
+
+def test_pn_gradients_vs_port():
+    torch.manual_seed(4)
+    ref = P.PortPN(64, 128, 3)
+    torch.manual_seed(4)
+    pn = inr.PN(64, 128, 3).cuda()
+    x0 = torch.rand(300, 64) * 2 - 1
+    tgt = torch.rand(300, 3)
+    ((ref(x0, 7, 0.5) - tgt) ** 2).mean().backward()
+    ((pn(x0.cuda(), 7, 0.5) - tgt.cuda()) ** 2).mean().backward()
+    for (n, a), (_, b) in zip(pn.named_parameters(), ref.named_parameters()):
+        assert O.rel_l2(host(a.grad), b.grad.numpy()) < T2, n
+
+
+def test_pn_phase_as_in_superresdwi(golden):
+    """superresDWI.py:147-156: PN -> input_mapping -> INR; with SRDWI.Siren the coordinates are detached, so the
+    PerturbNet receives no gradient (the reference's perturb_optim.step() is a no-op); with INRmodel.Siren it does."""
+    d = golden("dataset_ff.npz")
+    B = dev(d["B2"])
+    x = inr.input_mapping(inr.get_mgrid((16, 16)), B)
+    tgt = torch.rand(256, 1).cuda()
+    for flavor, expect_grad in (("SRDWI", False), ("INRmodel", True)):
+        torch.manual_seed(0)
+        net = inr.Siren(256, 64, 1, 1, flavor=flavor).cuda()
+        pn = inr.PN(256, 32, 2).cuda()
+        pert = inr.input_mapping(pn(x, 2, 1 / 128.), B)
+        out = net(pert)
+        if not expect_grad:
+            assert not out.requires_grad or pn.perturb_linear.weight.grad is None
+            continue
+        ((out - tgt) ** 2).mean().backward()
+        assert pn.perturb_linear.weight.grad is not None and torch.isfinite(pn.perturb_linear.weight.grad).all()
+        # same computation with the CPU port
+        torch.manual_seed(0)
+        rnet = P.PortSiren(256, 64, 1, 1, flavor=flavor)
+        rpn = P.PortPN(256, 32, 2)
+        rpn.load_state_dict({k: v.detach().cpu() for k, v in pn.state_dict().items()})
+        xr, Br = x.cpu(), B.cpu()
+        rout = rnet(P.port_input_mapping(rpn(xr, 2, 1 / 128.), Br))
+        ((rout - tgt.cpu()) ** 2).mean().backward()
+        assert O.rel_l2(host(out), rout.detach().numpy()) < T1
+        for (n, a), (_, b) in zip(pn.named_parameters(), rpn.named_parameters()):
+            assert O.rel_l2(host(a.grad), b.grad.numpy()) < 5e-5, n
