@@ -1,0 +1,163 @@
+"""Callers on either side of the hot path: the reference's driver loops restated on the fused entry points.
+
+* ``fit_volume``  -- superresDWI.py:84-162 / superresHybrid.py:79-125 for one N-D volume: max-normalise, LR =
+  every second in-plane sample, Fourier features, ``Siren(2m, 512, 3, 1)``, Adam 1e-4, full-batch MSE fit, dense
+  re-sampling at twice the HR in-plane grid ("x4" w.r.t. the LR grid), clamp at 0, PSNR/SSIM against the HR volume.
+* ``fit_slice_ensemble`` -- master.py:130-160: small raw-coordinate SIREN on K acquisitions of one 2-D slice, one
+  weighted optimizer step per acquisition per epoch, snapshot-ensemble of the last ``seg`` epochs at x1 and
+  x``scale``.
+* ``run_volumes`` -- the patient loop (superresDWI.py:29) partitioned over one-process-per-GPU ranks with a final
+  metric gather (``dist.py``).
+
+Everything numerical runs on the HIP kernels; these functions only orchestrate.
+"""
+from __future__ import annotations
+
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import dist as inr_dist
+from . import metrics
+from .inr import ImageFitting_set, Siren, SirenFitter, input_mapping, reconstruct
+
+
+def load_mat_volume(path: str, key: Optional[str] = None) -> np.ndarray:
+    """Reads one array from a MATLAB v5 ``.mat`` (``anon_data/patNN_mean_b0.mat``: key ``data_mean_b0``)."""
+    import scipy.io as sio
+    data = sio.loadmat(path)
+    if key is None:
+        keys = [k for k, v in data.items() if not k.startswith("__") and isinstance(v, np.ndarray) and v.ndim >= 2]
+        if len(keys) != 1:
+            raise KeyError(f"{path}: pass key=, candidates are {keys}")
+        key = keys[0]
+    return np.asarray(data[key])
+
+
+def fourier_matrix(dim: int, mapping_size: int = 128, scale: float = 0.5, seed: Optional[int] = None) -> np.ndarray:
+    """superresDWI.py:102-106: ``np.random.normal(size=(mapping_size, dim)) * scale`` as fp32 (seeded if asked)."""
+    rng = np.random if seed is None else np.random.RandomState(seed)
+    return (rng.normal(size=(mapping_size, dim)) * scale).astype(np.float32)
+
+
+def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512, hidden_layers: int = 3,
+               mapping_size: int = 128, ff_scale: float = 0.5, lr: float = 1e-4, seed: Optional[int] = 0,
+               downsample: bool = True, upscale_axes: int = 2, evaluate: bool = True, chunk_steps: int = 250,
+               return_recon: bool = True) -> Dict[str, object]:
+    """One INR super-resolution fit of an N-D volume (first ``upscale_axes`` axes are in-plane).
+
+    ``downsample=True``: the volume is the HR ground truth, training uses ``vol[::2, ::2, ...]`` and the result is
+    evaluated on the HR grid (PSNR, mean per-slice SSIM by the reference protocol) as well as re-sampled at 2x the
+    HR in-plane size.  ``downsample=False``: the volume itself is the training grid and is re-sampled at 2x.
+    """
+    vol = np.ascontiguousarray(volume, dtype=np.float32)
+    vmax = float(vol.max())
+    vol = np.ascontiguousarray(vol / vmax)                                                     # superresDWI.py:50-55
+    sl = tuple(slice(None, None, 2) if a < upscale_axes else slice(None) for a in range(vol.ndim))
+    lr_vol = np.ascontiguousarray(vol[sl]) if downsample else vol
+    hr_shape = vol.shape
+    test_shape = tuple(2 * s if a < upscale_axes else s for a, s in enumerate(hr_shape))
+    if seed is not None:
+        torch.manual_seed(seed)
+    B = torch.from_numpy(fourier_matrix(vol.ndim, mapping_size, ff_scale, seed)).cuda()
+    model = Siren(2 * mapping_size, hidden_features, hidden_layers, 1).cuda()
+    data = ImageFitting_set([lr_vol])
+    model_input = input_mapping(data.coords[0], B)                        # built once per fit (superresDWI.py:122)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fitter = SirenFitter(model, lr=lr)
+    losses = []
+    done = 0
+    while done < steps:
+        k = min(chunk_steps, steps - done)
+        losses.append(fitter.step(model_input, data.pixels[0], k))
+        done += k
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t0
+    fitter.release_workspace()
+    t0 = time.perf_counter()
+    recon = reconstruct(model, test_shape, B)                            # superresDWI.py:125-126,161
+    torch.cuda.synchronize()
+    t_rec = time.perf_counter() - t0
+    out: Dict[str, object] = {
+        "n_coords": int(lr_vol.size), "steps": int(steps), "t_fit": t_fit, "t_recon": t_rec,
+        "train_voxels_per_s": lr_vol.size * steps / t_fit, "recon_voxels_per_s": recon.numel() / t_rec,
+        "e2e_voxels_per_s": recon.numel() / (t_fit + t_rec), "final_loss": float(torch.cat(losses)[-1]) if steps else None,
+        "test_shape": test_shape, "scale_back": vmax,
+    }
+    if evaluate and downsample:
+        hr = torch.from_numpy(vol).cuda()
+        sr = reconstruct(model, hr_shape, B)                             # SR_recon on the HR grid (superresDWI.py:162)
+        out["psnr_db"] = float(metrics.psnr(hr, sr, 1.0))
+        if vol.ndim >= 2:
+            # per 2-D slice over the trailing axes, reference protocol (superresDWI.py:179-186)
+            perm = tuple(range(2, vol.ndim)) + (0, 1)
+            hs, ss = hr.permute(perm).contiguous(), sr.permute(perm).contiguous()
+            ok = hs.amax(dim=(-2, -1)) > 0
+            vals = metrics.ssim_reference_protocol(hs[ok].contiguous(), ss[ok].contiguous().clamp_min(1e-30)) \
+                if vol.ndim > 2 else metrics.ssim_reference_protocol(hs, ss)
+            out["ssim_mean"] = float(vals.mean())
+    if return_recon:
+        out["recon"] = recon
+    out["model"] = model
+    out["B"] = B
+    return out
+
+
+def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Sequence[np.ndarray]] = None,
+                       total_steps: int = 3000, seg: int = 150, scale: int = 3, hidden_features: int = 64,
+                       hidden_layers: int = 6, lr: float = 3e-4, seed: Optional[int] = 0) -> Dict[str, object]:
+    """master.py:130-160 for one gradient direction: raw 2-D coordinates -> Siren(2, H, L, 1); per epoch one weighted
+    Adam step per acquisition (targets are ``2*img-1``, nn_mri.py:174-180); the outputs of the last ``seg`` epochs at
+    the native and the x``scale`` grid are averaged.  Returns float64 host arrays like the reference."""
+    imgs = [np.asarray(a, np.float32) for a in acquisitions]
+    side = imgs[0].shape[0]
+    if any(a.shape != (side, side) for a in imgs):
+        raise ValueError("acquisitions must be square 2-D images of one size")
+    if seed is not None:
+        torch.manual_seed(seed)
+    model = Siren(2, hidden_features, hidden_layers, 1).cuda()
+    coords = ImageFitting_set([imgs[0]]).coords[0]                        # get_mgrid(side, 2)
+    targets = [(2.0 * torch.from_numpy(a) - 1.0).reshape(-1, 1).cuda() for a in imgs]
+    wts = None if weights is None else [torch.from_numpy(np.asarray(w, np.float32)).reshape(-1, 1).cuda()
+                                        for w in weights]
+    fitter = SirenFitter(model, lr=lr)
+    predicted = torch.zeros(side, side, dtype=torch.float64, device="cuda")
+    large = torch.zeros(side * scale, side * scale, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(total_steps):
+        for k, tgt in enumerate(targets):
+            fitter.step(coords, tgt, 1, None if wts is None else wts[k])
+        if step >= total_steps - seg:                                     # master.py:149-160
+            predicted += reconstruct(model, (side, side), None, clamp_min=None).double()
+            large += reconstruct(model, (side * scale, side * scale), None, clamp_min=None).double()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_snap = min(seg, total_steps)
+    return {"predicted": (predicted / max(n_snap, 1)).cpu().numpy(), "large": (large / max(n_snap, 1)).cpu().numpy(),
+            "seconds": dt, "optimizer_steps": total_steps * len(targets),
+            "train_voxels_per_s": total_steps * len(targets) * side * side / dt, "model": model}
+
+
+RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss")
+
+
+def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, **fit_kwargs) -> List[Dict[str, float]]:
+    """Fits every volume once, partitioned over the ranks of the current process group (LPT on coordinate count);
+    returns the gathered per-fit metric records on every rank (one RCCL all_gather)."""
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    costs = [float(np.prod([s // 2 if a < 2 else s for a, s in enumerate(v.shape)])) * steps for v in volumes]
+    plan = inr_dist.partition_fits(costs, world)
+    local = []
+    for job in plan[rank]:
+        res = fit_volume(volumes[job], steps=steps, return_recon=False, **fit_kwargs)
+        local.append({"job": job, "n_coords": res["n_coords"], "steps": steps, "t_fit": res["t_fit"],
+                      "t_recon": res["t_recon"], "psnr_db": res.get("psnr_db", float("nan")),
+                      "ssim_mean": res.get("ssim_mean", float("nan")), "final_loss": res["final_loss"]})
+    max_jobs = max(len(p) for p in plan) if plan else 0
+    records = inr_dist.gather_job_records(local, RECORD_KEYS, max(max_jobs, 1))
+    return sorted(records, key=lambda r: r["job"])
