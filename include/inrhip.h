@@ -59,6 +59,20 @@ typedef struct inr_siren_desc {
     float hidden_omega;
 } inr_siren_desc_t;
 
+/* RAMS multi-image network (multi-image-super-resolution/utils/network.py:91-155): RAMS(scale, filters, kernel_size,
+ * channels, r, N).  The kernels are written for filters == 32 and kernel_size == 3 (the reference's only
+ * configuration, multi-image-super-resolution/master.py:20-25). */
+typedef struct inr_rams_desc {
+    int   scale;        /* 3 */
+    int   filters;      /* 32 */
+    int   kernel_size;  /* 3 */
+    int   channels;     /* T = 9 acquisitions per stack */
+    int   r;            /* squeeze ratio 8 */
+    int   n_rfab;       /* N = 12 */
+    float mean;         /* 7433.6436 (network.py:18) */
+    float std;          /* 2353.0723 (network.py:19) */
+} inr_rams_desc_t;
+
 /* Flat parameter layout used by the fused entry points (network order):
  *   W_0[hidden][in], b_0[hidden], W_1[hidden][hidden], b_1, ..., W_head[out][hidden], b_head[out]
  * Every tensor starts at a multiple of 4 floats (16 B): offsets come from inr_siren_param_offsets. */
@@ -190,6 +204,24 @@ int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int he
                double data_range, int use_mask, float mask_thr, void* workspace, size_t workspace_bytes,
                void* stream);
 int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream);
+
+/* ---- a-13/a-14: RAMS forward + predict_tensor (network.py:91-155, prediction.py:76-83) --------------------------
+ * x [B][H][W][channels] fp32 (uint16-range values) -> out [B][scale*H][scale*W] fp32.  clip_round != 0 applies
+ * predict_tensor's clip to [0, 2^16] and round-half-to-even.
+ * `params` is ONE packed fp32 buffer with weight normalisation already folded (kernel = g*v/||v||, norm over every
+ * axis but the output channel); every segment starts at a multiple of 4 floats, in this order:
+ *   stem: w[27][32], b[32];
+ *   n_rfab x RFAB: conv1 w[27][32][32], b[32]; conv2 w, b; squeeze w[32][32/r], b[32/r]; excite w[32/r][32], b[32];
+ *   trunk conv w, b;
+ *   (channels/3) x { RFAB as above; reduction conv w[27][32][32], b[32] };
+ *   up conv w[27][32][32] (output channels scale^2, zero-padded to 32), b[32];
+ *   RTAB: conv1 w[9][T][T], b[T]; conv2 w, b; squeeze w[T][max(T/r,1)], b; excite w[max(T/r,1)][T], b[T];
+ *   global conv w[9][T][scale^2], b[scale^2].
+ * (conv kernels are in TensorFlow order: tap-major [k1][k2][k3], then input channel, then output channel.) */
+int64_t inr_rams_param_count(const inr_rams_desc_t* desc);
+size_t  inr_rams_workspace_bytes(const inr_rams_desc_t* desc, int batch, int height, int width);
+int inr_rams_forward(const inr_rams_desc_t* desc, const float* params, const float* x, float* out, int batch,
+                     int height, int width, int clip_round, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
  * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */

@@ -28,6 +28,11 @@ class SirenDesc(C.Structure):
                 ("out_features", C.c_int), ("first_omega", C.c_float), ("hidden_omega", C.c_float)]
 
 
+class RamsDesc(C.Structure):
+    _fields_ = [("scale", C.c_int), ("filters", C.c_int), ("kernel_size", C.c_int), ("channels", C.c_int),
+                ("r", C.c_int), ("n_rfab", C.c_int), ("mean", C.c_float), ("std", C.c_float)]
+
+
 class DeviceCaps(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("device", C.c_int), ("compute_units", C.c_int),
                 ("wavefront_size", C.c_int), ("lds_bytes_per_cu", C.c_int), ("clock_khz", C.c_int),
@@ -82,6 +87,10 @@ SIGNATURES = {
     "inr_ssim2d": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                              C.c_float, C.c_void_p, C.c_size_t, c_stream]),
     "inr_adc_map": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, c_stream]),
+    "inr_rams_param_count": (C.c_int64, [C.POINTER(RamsDesc)]),
+    "inr_rams_workspace_bytes": (C.c_size_t, [C.POINTER(RamsDesc), C.c_int, C.c_int, C.c_int]),
+    "inr_rams_forward": (C.c_int, [C.POINTER(RamsDesc), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, c_stream]),
     "inr_prof_enable": (C.c_int, [C.c_int]),
     "inr_prof_reset": (C.c_int, []),
     "inr_prof_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),

@@ -98,6 +98,10 @@ int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t p
 int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
                 int use_mask, float mask_thr, double* ws, hipStream_t st);
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
+long long rams_param_floats(const inr_rams_desc_t* d);
+size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W);
+int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
+                      int clip_round, float* ws, hipStream_t st);
 extern int g_force_generic;
 extern unsigned long long* g_stamps;
 
@@ -589,6 +593,44 @@ int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pix
     INR_REQUIRE(out && data && bvals, INR_E_INVALID, "inr_adc_map: null pointer");
     INR_REQUIRE(n_pixels >= 0 && n_b >= 2 && n_b <= 32, INR_E_INVALID, "inr_adc_map: need 2 <= n_b <= 32");
     return launch_adc(out, data, bvals, n_pixels, n_b, (hipStream_t)stream);
+}
+
+// ---- RAMS ------------------------------------------------------------------------------------------------
+static int check_rams(const inr_rams_desc_t* d) {
+    INR_REQUIRE(d != nullptr, INR_E_INVALID, "rams descriptor is null");
+    INR_REQUIRE(d->filters == 32 && d->kernel_size == 3, INR_E_INVALID,
+                "rams kernels need filters == 32 and kernel_size == 3 (got %d, %d)", d->filters, d->kernel_size);
+    INR_REQUIRE(d->scale >= 1 && d->scale * d->scale <= 32 && d->r >= 1 && d->filters / d->r >= 1 &&
+                    d->filters / d->r <= 8 && d->n_rfab >= 0,
+                INR_E_INVALID, "bad rams descriptor (scale=%d r=%d N=%d)", d->scale, d->r, d->n_rfab);
+    INR_REQUIRE(d->channels >= 3 && d->channels <= 32 && d->channels - 2 * (d->channels / 3) == 3, INR_E_INVALID,
+                "rams: channels must leave a temporal depth of 3 before the head (channels=%d)", d->channels);
+    return 0;
+}
+
+int64_t inr_rams_param_count(const inr_rams_desc_t* desc) {
+    if (check_rams(desc)) return INR_E_INVALID;
+    return rams_param_floats(desc);
+}
+
+size_t inr_rams_workspace_bytes(const inr_rams_desc_t* desc, int batch, int height, int width) {
+    if (check_rams(desc) || batch < 1 || height < 3 || width < 3) return 0;
+    return rams_workspace_floats(desc, batch, height, width) * sizeof(float);
+}
+
+int inr_rams_forward(const inr_rams_desc_t* desc, const float* params, const float* x, float* out, int batch, int height,
+                     int width, int clip_round, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_rams(desc)) return rc;
+    INR_REQUIRE(params && x && out, INR_E_INVALID, "inr_rams_forward: null pointer");
+    INR_REQUIRE(batch >= 1 && batch <= 65535 && height >= 3 && width >= 3, INR_E_INVALID,
+                "inr_rams_forward: bad sizes (B=%d H=%d W=%d)", batch, height, width);
+    INR_REQUIRE((long long)(height + 4) * (width + 4) * desc->channels * 32 * 4 < (1ll << 31), INR_E_INVALID,
+                "inr_rams_forward: one image's activations must stay below 2 GiB");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_workspace_bytes(desc, batch, height, width), INR_E_WORKSPACE,
+                "inr_rams_forward: workspace too small");
+    INR_REQUIRE(aligned16(workspace) && aligned16(params), INR_E_ALIGN, "inr_rams_forward: params/workspace alignment");
+    return rams_forward_impl(desc, params, x, out, batch, height, width, clip_round, (float*)workspace,
+                             (hipStream_t)stream);
 }
 
 // ---- profiler --------------------------------------------------------------------------------------------

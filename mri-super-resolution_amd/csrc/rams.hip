@@ -1,0 +1,469 @@
+// RAMS multi-image super-resolution network, forward pass:
+//   /root/reference/multi-image-super-resolution/utils/network.py:91-155 (graph), :42-63 RFAB, :65-87 RTAB,
+//   :37-39 reflective padding, :21-27 normalize/denormalize; utils/prediction.py:76-83 predict_tensor.
+// Activations are NDHWC fp32 exactly as the reference's Keras graph keeps them: [B][H'][W'][T][32].
+//
+// The work is 25 + 4 3x3x3 convolutions 32 -> 32 (>= 99 % of the 265 GFLOP): `conv3d_c32_mfma_kernel` runs them
+// as an implicit GEMM on v_mfma_f32_32x32x2_f32 -- M = 32 output voxels per wave tile, N = 32 output channels,
+// K = 27 taps x 32 input channels.  The whole folded kernel (27x32x32 fp32 = 108 KB) sits in LDS for the life of
+// the block (8 waves / CU share it); the A operand is read straight from global memory (each voxel's 32 channels
+// are one 128-B line, re-used by 27 taps out of L1/L2) through a buffer resource, so 'same' zero padding and the
+// ragged last tile are plain out-of-range reads that return 0 -- no halo staging, no branches.  Bias, ReLU and the
+// per-channel sums needed by the attention block's global average pool are fused into the epilogue.
+// Everything else (stem 1 -> 32 conv, 1x1x1 squeeze/excite gates, reflect padding, the 2-D branch, pixel shuffle)
+// is < 1 % of the work and uses simple direct kernels.
+// Weight normalisation (tfa WeightNormalization, g*v/||v||) is folded into the kernels when the parameters are
+// packed (host side, once per model) -- the packed layouts are documented in include/inrhip.h.
+#include "common.h"
+
+namespace inr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RC = 32;                      // feature channels of the 3-D trunk (network.py: filters = 32)
+constexpr int CONV_THREADS = 512;           // 8 waves share one LDS copy of the kernel
+constexpr int CONV_W_FLOATS = 27 * RC * RC;
+
+struct Conv3dParams {
+    const float* x;       // [B][D1][D2][D3][32]
+    float* y;             // [B][O1][O2][O3][y_cstride]
+    const float* w;       // [27][32 cin][32 cout] (cout zero-padded to 32)
+    const float* bias;    // [32]
+    float* chan_slab;     // nullable: [B][waves_per_b][32] per-channel sums of the (post-activation) output
+    int B, D1, D2, D3, O1, O2, O3;
+    int pad;              // 1 = 'same' (zero padding), 0 = 'valid'
+    int cout, y_cstride;  // channels actually stored / channel stride of y
+    int relu;
+    int tiles_per_b, waves_per_b;
+    long long x_elems_per_b;
+};
+
+__global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const Conv3dParams p) {
+    __shared__ __attribute__((aligned(16))) float sw[CONV_W_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int b = blockIdx.y;
+    for (int i = tid; i < CONV_W_FLOATS / 4; i += CONV_THREADS)
+        reinterpret_cast<f32x4*>(sw)[i] = reinterpret_cast<const f32x4*>(p.w)[i];
+    __syncthreads();
+
+    const long long xbytes = p.x_elems_per_b * 4;
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x + (long long)b * p.x_elems_per_b), 0, (int)(unsigned)(xbytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : xbytes),
+        0x00020000);
+    const int ovox = p.O1 * p.O2 * p.O3;
+    const float bias = p.bias[l32];
+    float csum = 0.f;
+
+    for (int tile = blockIdx.x * (CONV_THREADS / 64) + wave; tile < p.tiles_per_b; tile += p.waves_per_b) {
+        const int v = tile * 32 + l32;
+        const bool vvalid = v < ovox;
+        const int o3 = v % p.O3, o2 = (v / p.O3) % p.O2, o1 = v / (p.O3 * p.O2);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        auto load_tap = [&](int tap, f32x4(&a)[4]) {
+            const int d1 = tap / 9, d2 = (tap / 3) % 3, d3 = tap % 3;
+            const int i1 = o1 + d1 - p.pad, i2 = o2 + d2 - p.pad, i3 = o3 + d3 - p.pad;
+            const bool ok = vvalid && (unsigned)i1 < (unsigned)p.D1 && (unsigned)i2 < (unsigned)p.D2 &&
+                            (unsigned)i3 < (unsigned)p.D3;
+            // channel offset of this lane half inside an 8-wide k block is 4h; out-of-range -> offset past the SRD
+            const int off = ok ? ((((i1 * p.D2 + i2) * p.D3 + i3) * RC + 4 * h) * 4) : 0x7FFFFF00;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, off + q * 32, 0, 0));
+        };
+
+        f32x4 a_cur[4], a_nxt[4];
+        load_tap(0, a_cur);
+#pragma unroll 1
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) load_tap(tap + 1, a_nxt);
+            const float* wt = sw + tap * RC * RC + l32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float bv = wt[(8 * q + 4 * h + s) * RC];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][s], bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+        }
+
+        // epilogue: C/D map col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4h (voxel inside the tile)
+        float tsum = 0.f;
+        float* yb = p.y + ((long long)b * ovox + (long long)tile * 32) * p.y_cstride + l32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float o = acc[r] + bias;
+            if (p.relu) o = fmaxf(o, 0.f);
+            if (tile * 32 + row < ovox) {
+                tsum += o;
+                if (l32 < p.cout) yb[(long long)row * p.y_cstride] = o;
+            }
+        }
+        if (p.chan_slab) csum += tsum + __shfl_xor(tsum, 32, 64);
+    }
+    if (p.chan_slab && lane < 32)
+        p.chan_slab[((long long)b * p.waves_per_b + blockIdx.x * (CONV_THREADS / 64) + wave) * RC + lane] = csum;
+}
+
+// ---- stem: Conv3D 1 -> 32, 3x3x3 'same' (network.py:119) ----------------------------------------------------
+// x [B][D1][D2][D3], w [27][32], y [B][D1][D2][D3][32]; one thread per (voxel, cout)
+__global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int B, int D1, int D2, int D3) {
+    const long long total = (long long)B * D1 * D2 * D3 * RC;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % RC);
+    long long v = i / RC;
+    const int i3 = (int)(v % D3); v /= D3;
+    const int i2 = (int)(v % D2); v /= D2;
+    const int i1 = (int)(v % D1);
+    const int b = (int)(v / D1);
+    float acc = bias[c];
+    for (int d1 = 0; d1 < 3; ++d1)
+        for (int d2 = 0; d2 < 3; ++d2)
+            for (int d3 = 0; d3 < 3; ++d3) {
+                const int j1 = i1 + d1 - 1, j2 = i2 + d2 - 1, j3 = i3 + d3 - 1;
+                if ((unsigned)j1 < (unsigned)D1 && (unsigned)j2 < (unsigned)D2 && (unsigned)j3 < (unsigned)D3)
+                    acc = fmaf(x[(((long long)b * D1 + j1) * D2 + j2) * D3 + j3], w[((d1 * 3 + d2) * 3 + d3) * RC + c], acc);
+            }
+    y[i] = acc;
+}
+
+// ---- attention gate: global average pool finish + 1x1 squeeze (ReLU) + 1x1 excite (sigmoid) ---------------------
+// slab [B][nslab][C] partial channel sums -> gate [B][C].  One block per batch element.
+__global__ void __launch_bounds__(256) gate_kernel(float* __restrict__ gate, const float* __restrict__ slab, int nslab,
+                                                   float inv_count, const float* __restrict__ wsq /*[C][Cr]*/,
+                                                   const float* __restrict__ bsq, const float* __restrict__ wex /*[Cr][C]*/,
+                                                   const float* __restrict__ bex, int C, int Cr) {
+    __shared__ float part[256];
+    __shared__ float mean[32];
+    __shared__ float sq[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int c = t % 32, ph = t / 32;  // 8 phases
+    float acc = 0.f;
+    if (c < C)
+        for (int s = ph; s < nslab; s += 8) acc += slab[((long long)b * nslab + s) * C + c];
+    part[t] = acc;
+    __syncthreads();
+    if (t < C) {
+        float m = 0.f;
+        for (int k = 0; k < 8; ++k) m += part[k * 32 + t];
+        mean[t] = m * inv_count;
+    }
+    __syncthreads();
+    if (t < Cr) {
+        float s = bsq[t];
+        for (int k = 0; k < C; ++k) s = fmaf(mean[k], wsq[k * Cr + t], s);
+        sq[t] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    if (t < C) {
+        float e = bex[t];
+        for (int k = 0; k < Cr; ++k) e = fmaf(sq[k], wex[k * C + t], e);
+        gate[b * C + t] = 1.0f / (1.0f + expf(-e));
+    }
+}
+
+// out = y * gate[b][c] + res   over [B][per_b voxels][C]
+__global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__ out, const float* __restrict__ y,
+                                                             const float* __restrict__ gate, const float* __restrict__ res,
+                                                             long long per_b, int C, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const int b = (int)(i / (per_b * C));
+    out[i] = fmaf(y[i], gate[b * C + c], res[i]);
+}
+
+__global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                  const float* __restrict__ b, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = a[i] + b[i];
+}
+
+// (x - MEAN)/STD  (network.py:21-23)
+__global__ void __launch_bounds__(256) normalize_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                        long long total, float mean, float stdv) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = (x[i] - mean) / stdv;
+}
+
+// tf.pad REFLECT by 1 on axes 1,2 of [B][D1][D2][inner]  (network.py:37-39,145)
+__global__ void __launch_bounds__(256) reflect_pad_kernel(float* __restrict__ out, const float* __restrict__ x, int B,
+                                                          int D1, int D2, int inner) {
+    const long long total = (long long)B * (D1 + 2) * (D2 + 2) * inner;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % inner);
+    long long v = i / inner;
+    const int o2 = (int)(v % (D2 + 2)); v /= (D2 + 2);
+    const int o1 = (int)(v % (D1 + 2));
+    const int b = (int)(v / (D1 + 2));
+    int i1 = o1 - 1, i2 = o2 - 1;
+    i1 = i1 < 0 ? -i1 : (i1 >= D1 ? 2 * D1 - 2 - i1 : i1);
+    i2 = i2 < 0 ? -i2 : (i2 >= D2 ? 2 * D2 - 2 - i2 : i2);
+    out[i] = x[(((long long)b * D1 + i1) * D2 + i2) * inner + k];
+}
+
+// ---- 2-D branch (RTAB on the 9 normalised inputs, network.py:145-148): direct kernels ----------------------------
+// x [B][D1][D2][Cin], w [9 taps][Cin][Cout], y [B][O1][O2][Cout]; thread per (pixel, cout)
+__global__ void __launch_bounds__(256) conv2d_direct_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int B, int D1, int D2, int Cin, int Cout, int pad, int relu) {
+    const int O1 = D1 + 2 * pad - 2, O2 = D2 + 2 * pad - 2;
+    const long long total = (long long)B * O1 * O2 * Cout;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % Cout);
+    long long v = i / Cout;
+    const int o2 = (int)(v % O2); v /= O2;
+    const int o1 = (int)(v % O1);
+    const int b = (int)(v / O1);
+    float acc = bias[c];
+    for (int d1 = 0; d1 < 3; ++d1)
+        for (int d2 = 0; d2 < 3; ++d2) {
+            const int j1 = o1 + d1 - pad, j2 = o2 + d2 - pad;
+            if ((unsigned)j1 < (unsigned)D1 && (unsigned)j2 < (unsigned)D2) {
+                const float* xp = x + (((long long)b * D1 + j1) * D2 + j2) * Cin;
+                const float* wp = w + (d1 * 3 + d2) * Cin * Cout + c;
+                for (int k = 0; k < Cin; ++k) acc = fmaf(xp[k], wp[k * Cout], acc);
+            }
+        }
+    y[i] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+// slab[b][blk][C] = partial channel sums of x [B][per_b][C]  (C <= 32; feeds gate_kernel)
+__global__ void __launch_bounds__(256) chan_partial_kernel(float* __restrict__ slab, const float* __restrict__ x,
+                                                           long long per_b, int C, int nblk) {
+    __shared__ float part[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int c = t % 32, ph = t / 32;
+    float acc = 0.f;
+    if (c < C)
+        for (long long v = (long long)blockIdx.x * 8 + ph; v < per_b; v += (long long)nblk * 8)
+            acc += x[((long long)b * per_b + v) * C + c];
+    part[t] = acc;
+    __syncthreads();
+    if (t < C) {
+        float s = 0.f;
+        for (int k = 0; k < 8; ++k) s += part[k * 32 + t];
+        slab[((long long)b * nblk + blockIdx.x) * C + t] = s;
+    }
+}
+
+// final assembly (network.py:140-152 + prediction.py:76-83):
+// out[b][s*h+i][s*w+j] = (up[b][h][w][i*s+j] + glob[b][h][w][i*s+j]) * STD + MEAN ; optional clip [0, 2^16] + round-half-even
+__global__ void __launch_bounds__(256) shuffle_sum_kernel(float* __restrict__ out, const float* __restrict__ up,
+                                                          const float* __restrict__ glob, int B, int H, int W, int s,
+                                                          float mean, float stdv, int clip_round) {
+    const long long total = (long long)B * H * s * W * s;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ow = (int)(i % (W * s));
+    long long v = i / (W * s);
+    const int oh = (int)(v % (H * s));
+    const int b = (int)(v / (H * s));
+    const int hh = oh / s, ii = oh % s, ww = ow / s, jj = ow % s;
+    const long long src = (((long long)b * H + hh) * W + ww) * (s * s) + ii * s + jj;
+    float o = (up[src] + glob[src]) * stdv + mean;
+    if (clip_round) o = rintf(fminf(fmaxf(o, 0.f), 65536.f));
+    out[i] = o;
+}
+
+// =============================== host orchestration ====================================================
+static inline unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
+
+struct RamsLayout {
+    // offsets (floats) into the packed parameter buffer; see inr_rams_param_offsets
+    long long stem_w, stem_b;
+    long long total;
+};
+
+// packed-parameter walk: conv3d 32->32 block = [27*32*32 w][32 b]; gate = [C*Cr][Cr][Cr*C][C]
+struct Cursor {
+    const float* base;
+    long long off = 0;
+    const float* take(long long n) {
+        const float* p = base + off;
+        off += (n + 3) / 4 * 4;
+        return p;
+    }
+};
+
+long long rams_param_floats(const inr_rams_desc_t* d) {
+    Cursor c{nullptr};
+    auto conv = [&]() { c.take(CONV_W_FLOATS); c.take(RC); };
+    auto gate = [&](int C, int Cr) { c.take((long long)C * Cr); c.take(Cr); c.take((long long)Cr * C); c.take(C); };
+    const int Cr = d->filters / d->r;
+    c.take(27 * RC); c.take(RC);                       // stem
+    for (int i = 0; i < d->n_rfab; ++i) { conv(); conv(); gate(RC, Cr); }
+    conv();                                            // trunk
+    for (int i = 0; i < d->channels / 3; ++i) { conv(); conv(); gate(RC, Cr); conv(); }
+    conv();                                            // up (cout padded to 32)
+    const int T = d->channels, Tr = T / d->r > 0 ? T / d->r : 1;
+    c.take(9LL * T * T); c.take(T); c.take(9LL * T * T); c.take(T);  // rtab conv1, conv2
+    gate(T, Tr);
+    c.take(9LL * T * d->scale * d->scale); c.take(d->scale * d->scale);  // global conv
+    return c.off;
+}
+
+static int conv3d_mfma(const float* x, float* y, const float* w, const float* bias, float* chan_slab, int B, int D1,
+                       int D2, int D3, int pad, int cout, int y_cstride, int relu, int waves_per_b, hipStream_t st) {
+    Conv3dParams p{};
+    p.x = x; p.y = y; p.w = w; p.bias = bias; p.chan_slab = chan_slab;
+    p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
+    p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
+    p.pad = pad; p.cout = cout; p.y_cstride = y_cstride; p.relu = relu;
+    const int ovox = p.O1 * p.O2 * p.O3;
+    p.tiles_per_b = (ovox + 31) / 32;
+    p.waves_per_b = waves_per_b;
+    p.x_elems_per_b = (long long)D1 * D2 * D3 * RC;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(conv3d_c32_mfma_kernel, dim3(waves_per_b / (CONV_THREADS / 64), B), dim3(CONV_THREADS), 0, st, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// number of waves per batch element for the conv kernel: fill the chip once, never more waves than tiles
+int rams_waves_per_b(int B, int ovox) {
+    const int tiles = (ovox + 31) / 32;
+    int blocks = (256 + B - 1) / B;                 // ~one block per CU in total
+    if (blocks < 1) blocks = 1;
+    const int max_blocks = (tiles + 7) / 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    return blocks * 8;
+}
+
+size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W) {
+    const long long T = d->channels;
+    const long long big = (long long)B * (H + 4) * (W + 4) * T * RC;      // largest 5-D activation (padded reduction stage)
+    const long long slab = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * (int)T) * RC + 4096;
+    const long long small = (long long)B * (H + 2) * (W + 2) * T * 4 + (long long)B * H * W * d->scale * d->scale * 2;
+    return (size_t)(5 * big + slab + small + 8192);
+}
+
+int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
+                      int clip_round, float* ws, hipStream_t st) {
+    const int T = d->channels, Cr = d->filters / d->r, S2 = d->scale * d->scale;
+    const int Tr = T / d->r > 0 ? T / d->r : 1;
+    const long long big = (long long)B * (H + 4) * (W + 4) * T * RC;
+    float* bufA = ws;               // current trunk activation
+    float* bufB = bufA + big;       // conv1 output
+    float* bufC = bufB + big;       // conv2 output (to be gated)
+    float* bufR = bufC + big;       // trunk residual (stem output)
+    float* bufP = bufR + big;       // padded copies
+    float* slab = bufP + big;
+    const long long slab_floats = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * T) * RC + 4096;
+    float* gate = slab + slab_floats - 2048;         // [B][32]
+    float* xn = slab + slab_floats;                  // normalised input [B][H][W][T]
+    float* xpad = xn + (long long)B * H * W * T;     // reflect-padded [B][H+2][W+2][T]
+    float* g1 = xpad + (long long)B * (H + 2) * (W + 2) * T;
+    float* g2 = g1 + (long long)B * (H + 2) * (W + 2) * T;
+    float* upo = g2 + (long long)B * (H + 2) * (W + 2) * T;   // [B][H][W][S2]
+    float* glo = upo + (long long)B * H * W * S2;
+    Cursor c{params};
+
+    auto rfab = [&](float* io, int D1, int D2, int D3) -> int {   // io updated in place: io = gate*conv2(relu(conv1(io))) + io
+        const float* w1 = c.take(CONV_W_FLOATS); const float* b1 = c.take(RC);
+        const float* w2 = c.take(CONV_W_FLOATS); const float* b2 = c.take(RC);
+        const float* wsq = c.take((long long)RC * Cr); const float* bsq = c.take(Cr);
+        const float* wex = c.take((long long)Cr * RC); const float* bex = c.take(RC);
+        const int ovox = D1 * D2 * D3;
+        const int wpb = rams_waves_per_b(B, ovox);
+        if (int rc = conv3d_mfma(io, bufB, w1, b1, nullptr, B, D1, D2, D3, 1, RC, RC, 1, wpb, st)) return rc;
+        if (int rc = conv3d_mfma(bufB, bufC, w2, b2, slab, B, D1, D2, D3, 1, RC, RC, 0, wpb, st)) return rc;
+        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, wpb, 1.0f / (float)ovox, wsq, bsq, wex, bex,
+                           RC, Cr);
+        INR_LAUNCH_CHECK();
+        const long long total = (long long)B * ovox * RC;
+        hipLaunchKernelGGL(scale_residual_kernel, dim3(nblk(total)), dim3(256), 0, st, io, bufC, gate, io, (long long)ovox,
+                           RC, total);
+        INR_LAUNCH_CHECK();
+        return 0;
+    };
+
+    ProfScope ps(KC_OTHER, st);
+    // normalise, lift, reflect-pad (network.py:113-116)
+    const long long n_in = (long long)B * H * W * T;
+    hipLaunchKernelGGL(normalize_kernel, dim3(nblk(n_in)), dim3(256), 0, st, xn, x, n_in, d->mean, d->std);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(nblk((long long)B * (H + 2) * (W + 2) * T)), dim3(256), 0, st, xpad, xn, B, H,
+                       W, T);
+    INR_LAUNCH_CHECK();
+    int D1 = H + 2, D2 = W + 2, D3 = T;
+    {   // stem (network.py:119)
+        const float* w = c.take(27 * RC); const float* b = c.take(RC);
+        hipLaunchKernelGGL(conv3d_c1_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * RC)), dim3(256), 0, st, bufA, xpad, w, b,
+                           B, D1, D2, D3);
+        INR_LAUNCH_CHECK();
+    }
+    INR_HIP(hipMemcpyAsync(bufR, bufA, (size_t)B * D1 * D2 * D3 * RC * 4, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < d->n_rfab; ++i)
+        if (int rc = rfab(bufA, D1, D2, D3)) return rc;
+    {   // trunk close + long skip (network.py:127-129)
+        const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
+        const int wpb = rams_waves_per_b(B, D1 * D2 * D3);
+        if (int rc = conv3d_mfma(bufA, bufB, w, b, nullptr, B, D1, D2, D3, 1, RC, RC, 0, wpb, st)) return rc;
+        const long long total = (long long)B * D1 * D2 * D3 * RC;
+        hipLaunchKernelGGL(add_kernel, dim3(nblk(total)), dim3(256), 0, st, bufA, bufB, bufR, total);
+        INR_LAUNCH_CHECK();
+    }
+    for (int i = 0; i < T / 3; ++i) {   // temporal reduction (network.py:132-136)
+        hipLaunchKernelGGL(reflect_pad_kernel, dim3(nblk((long long)B * (D1 + 2) * (D2 + 2) * D3 * RC)), dim3(256), 0, st, bufP,
+                           bufA, B, D1, D2, D3 * RC);
+        INR_LAUNCH_CHECK();
+        if (int rc = rfab(bufP, D1 + 2, D2 + 2, D3)) return rc;
+        const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
+        const int wpb = rams_waves_per_b(B, D1 * D2 * (D3 - 2));
+        if (int rc = conv3d_mfma(bufP, bufA, w, b, nullptr, B, D1 + 2, D2 + 2, D3, 0, RC, RC, 1, wpb, st)) return rc;
+        D3 -= 2;
+    }
+    {   // up-scaling head: Conv3D 32 -> scale^2, valid; keep T index 0 (network.py:139-140)
+        const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
+        INR_REQUIRE(D3 == 3, INR_E_INVALID, "rams: temporal depth before the head must be 3 (got %d)", D3);
+        const int wpb = rams_waves_per_b(B, (D1 - 2) * (D2 - 2));
+        if (int rc = conv3d_mfma(bufA, upo, w, b, nullptr, B, D1, D2, D3, 0, S2, S2, 0, wpb, st)) return rc;
+    }
+    {   // global residual path: RTAB on the padded normalised input + valid conv (network.py:145-148)
+        const float* w1 = c.take(9LL * T * T); const float* b1 = c.take(T);
+        const float* w2 = c.take(9LL * T * T); const float* b2 = c.take(T);
+        const float* wsq = c.take((long long)T * Tr); const float* bsq = c.take(Tr);
+        const float* wex = c.take((long long)Tr * T); const float* bex = c.take(T);
+        const float* wg = c.take(9LL * T * S2); const float* bg = c.take(S2);
+        const int P1 = H + 2, P2 = W + 2;
+        const long long tot = (long long)B * P1 * P2 * T;
+        hipLaunchKernelGGL(conv2d_direct_kernel, dim3(nblk(tot)), dim3(256), 0, st, g1, xpad, w1, b1, B, P1, P2, T, T, 1, 1);
+        INR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv2d_direct_kernel, dim3(nblk(tot)), dim3(256), 0, st, g2, g1, w2, b2, B, P1, P2, T, T, 1, 0);
+        INR_LAUNCH_CHECK();
+        const int nb2 = 64;
+        hipLaunchKernelGGL(chan_partial_kernel, dim3(nb2, B), dim3(256), 0, st, slab, g2, (long long)P1 * P2, T, nb2);
+        INR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, nb2, 1.0f / (float)(P1 * P2), wsq, bsq, wex, bex,
+                           T, Tr);
+        INR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(scale_residual_kernel, dim3(nblk(tot)), dim3(256), 0, st, g1, g2, gate, xpad, (long long)P1 * P2, T,
+                           tot);
+        INR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv2d_direct_kernel, dim3(nblk((long long)B * H * W * S2)), dim3(256), 0, st, glo, g1, wg, bg, B, P1,
+                           P2, T, S2, 0, 0);
+        INR_LAUNCH_CHECK();
+    }
+    const long long n_out = (long long)B * H * d->scale * W * d->scale;
+    hipLaunchKernelGGL(shuffle_sum_kernel, dim3(nblk(n_out)), dim3(256), 0, st, out, upo, glo, B, H, W, d->scale, d->mean,
+                       d->std, clip_round);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace inr

@@ -1,0 +1,150 @@
+"""RAMS multi-image super-resolution (forward / inference) on the HIP kernels.
+
+Mirrors the reference's surface: ``RAMS(scale, filters, kernel_size, channels, r, N)``
+(multi-image-super-resolution/utils/network.py:91-155) returns a callable model, ``predict_tensor(model, x)`` is
+utils/prediction.py:76-83, ``predict_case`` is the 25-random-subsets loop of
+multi-image-super-resolution/master.py:43-52 (run as ONE batched forward).
+
+Parameters are kept in the reference's form -- per layer the WeightNormalization variables ``v`` (TensorFlow kernel
+layout ``[k..., Cin, Cout]``), ``g`` (``[Cout]``) and the bias ``b`` -- in ``model.params`` (numpy, name -> array;
+layer names as in ``rams_layer_names``).  ``model.pack()`` folds ``g*v/||v||`` and lays everything out as the one
+flat device buffer ``inr_rams_forward`` consumes (layout: include/inrhip.h).  No TensorFlow checkpoint reader is
+provided: the shipped checkpoints are incomplete.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import RamsDesc, check, lib
+
+MEAN = 7433.6436   # network.py:18
+STD = 2353.0723    # network.py:19
+
+
+def rams_layer_specs(scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
+    """[(name, kernel_spatial_shape, cin, cout)] in graph order (network.py:119-147)."""
+    k3, k2 = (kernel_size,) * 3, (kernel_size,) * 2
+    specs = [("stem", k3, 1, filters)]
+
+    def rfab(prefix):
+        return [(f"{prefix}/conv1", k3, filters, filters), (f"{prefix}/conv2", k3, filters, filters),
+                (f"{prefix}/squeeze", (1, 1, 1), filters, int(filters / r)),
+                (f"{prefix}/excite", (1, 1, 1), int(filters / r), filters)]
+
+    for i in range(N):
+        specs += rfab(f"rfab{i}")
+    specs.append(("trunk", k3, filters, filters))
+    for i in range(channels // 3):
+        specs += rfab(f"red{i}/rfab")
+        specs.append((f"red{i}/conv", (3, 3, 3), filters, filters))
+    specs.append(("up", (3, 3, 3), filters, scale ** 2))
+    specs += [("rtab/conv1", k2, 9, 9), ("rtab/conv2", k2, 9, 9), ("rtab/squeeze", (1, 1), 9, int(9 / r)),
+              ("rtab/excite", (1, 1), int(9 / r), 9), ("global", (3, 3), 9, scale ** 2)]
+    return specs
+
+
+class RAMS:
+    """``RAMS(scale, filters, kernel_size, channels, r, N)``; call it on ``[B, H, W, channels]`` data."""
+
+    def __init__(self, scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12, params=None, seed=None):
+        self.cfg = dict(scale=scale, filters=filters, kernel_size=kernel_size, channels=channels, r=r, N=N)
+        self.desc = RamsDesc(scale, filters, kernel_size, channels, r, N, MEAN, STD)
+        self.specs = rams_layer_specs(**self.cfg)
+        if params is None:   # Keras defaults: glorot-uniform kernels, zero bias; WeightNormalization g = ||v||
+            rng = np.random.default_rng(seed)
+            params = {}
+            for name, ks, cin, cout in self.specs:
+                fan_in, fan_out = int(np.prod(ks)) * cin, int(np.prod(ks)) * cout
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                v = rng.uniform(-lim, lim, size=ks + (cin, cout)).astype(np.float32)
+                params[f"{name}/v"] = v
+                params[f"{name}/g"] = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(v.ndim - 1)))).astype(np.float32)
+                params[f"{name}/b"] = np.zeros(cout, np.float32)
+        self.params = params
+        self._packed = None
+
+    # ---- parameter packing ---------------------------------------------------------------------------------
+    def folded_kernel(self, name):
+        v = self.params[f"{name}/v"].astype(np.float64)
+        norm = np.sqrt((v ** 2).sum(axis=tuple(range(v.ndim - 1)), keepdims=True))
+        return (self.params[f"{name}/g"].astype(np.float64) * v / norm).astype(np.float32)
+
+    def pack(self):
+        """Flat device buffer in the layout of include/inrhip.h (every segment padded to 4 floats)."""
+        if self._packed is not None:
+            return self._packed
+        segs = []
+
+        def put(a):
+            a = np.ascontiguousarray(a, np.float32).reshape(-1)
+            pad = (-a.size) % 4
+            segs.append(np.concatenate([a, np.zeros(pad, np.float32)]) if pad else a)
+
+        for name, ks, cin, cout in self.specs:
+            w = self.folded_kernel(name).reshape(-1, cin, cout)        # TF order is already [tap][cin][cout]
+            b = self.params[f"{name}/b"]
+            if name == "up":                                           # zero-pad the output channels to the tile width
+                w = np.concatenate([w, np.zeros(w.shape[:2] + (32 - cout,), np.float32)], axis=2)
+                b = np.concatenate([b, np.zeros(32 - cout, np.float32)])
+            if name == "stem":
+                w = w.reshape(27, cout)
+            put(w)
+            put(b)
+        flat = np.concatenate(segs)
+        want = lib().inr_rams_param_count(C.byref(self.desc))
+        if want < 0:
+            check(int(want), "inr_rams_param_count")
+        if flat.size != want:
+            raise RuntimeError(f"packed RAMS parameters have {flat.size} floats, the library expects {want}")
+        ops.require_gpu()
+        self._packed = torch.from_numpy(flat).cuda()
+        return self._packed
+
+    def invalidate(self):
+        self._packed = None
+
+    # ---- forward ---------------------------------------------------------------------------------------------
+    def forward(self, x, clip_round=False):
+        """x: ``[B, H, W, channels]`` (numpy or tensor, any real dtype; cast to fp32 like prediction.py:78).
+        Returns a device tensor ``[B, scale*H, scale*W, 1]``."""
+        dev = ops.require_gpu()
+        xt = torch.as_tensor(np.asarray(x, np.float32) if not torch.is_tensor(x) else x).to(dev, torch.float32).contiguous()
+        if xt.dim() != 4 or xt.shape[-1] != self.cfg["channels"]:
+            raise ValueError(f"input must be [B, H, W, {self.cfg['channels']}], got {tuple(xt.shape)}")
+        B, H, W, _ = xt.shape
+        s = self.cfg["scale"]
+        out = torch.empty((B, H * s, W * s, 1), dtype=torch.float32, device=dev)
+        nbytes = lib().inr_rams_workspace_bytes(C.byref(self.desc), B, H, W)
+        if nbytes == 0:
+            check(-1, "inr_rams_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(lib().inr_rams_forward(C.byref(self.desc), self.pack().data_ptr(), xt.data_ptr(), out.data_ptr(), B, H, W,
+                                     1 if clip_round else 0, ws.data_ptr(), ws.numel(), ops._stream()),
+              "inr_rams_forward")
+        return out
+
+    __call__ = forward
+
+
+def predict_tensor(model: RAMS, x):
+    """utils/prediction.py:76-83: cast to fp32 -> model -> clip to [0, 2**16] -> round (half to even)."""
+    return model.forward(x, clip_round=True)
+
+
+def predict_case(model: RAMS, stack, sample_size=25, rng=None):
+    """multi-image-super-resolution/master.py:38-52: ``stack`` is one slice ``[H, W, T]`` of the DWI series; it is cast
+    to uint16, multiplied by 256, ``sample_size`` random 9-acquisition subsets are super-resolved and averaged.
+    The subsets run as one batch (the per-subset results are independent)."""
+    import random
+    rng = rng or random
+    lor = np.asarray(stack)[None].astype("uint16") * 256
+    T = lor.shape[3]
+    ch = model.cfg["channels"]
+    subsets = [rng.sample(list(range(T)), ch) for _ in range(sample_size)]
+    batch = np.concatenate([lor[:, :, :, inx] for inx in subsets], axis=0).astype(np.float32)
+    sr = predict_tensor(model, batch)[..., 0]
+    return sr.double().mean(dim=0), subsets

@@ -1,0 +1,12 @@
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mri_super_resolution_amd import rams, ops
+model = rams.RAMS(seed=0)
+for B in (1, 5, 25):
+    x = (np.random.default_rng(0).random((B, 128, 128, 9)) * 60000).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    model(xt); torch.cuda.synchronize()
+    t0 = time.perf_counter(); reps = 3
+    for _ in range(reps): model(xt)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    print(f"RAMS forward B={B}: {dt*1e3:.2f} ms  -> {265.0*B/dt/1e3:.1f} TFLOP/s (265 GFLOP per 128x128x9 stack), {B/dt:.1f} stacks/s")
