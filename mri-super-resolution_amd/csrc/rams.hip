@@ -40,6 +40,12 @@ struct Conv3dParams {
     long long x_elems_per_b;
 };
 
+// MT = output tiles (32 voxels each) a wave works on at once; they share every B fragment read from LDS.
+// Per tap: a tap's input offset is the lane's base offset (VGPR, once per tile) plus a wave-uniform
+// delta (one add), and a tap's in-bounds predicate is one bit of a per-lane 27-bit
+// mask built once per tile -- the f32 MFMA shares the VALU lanes, so per-tap address arithmetic is kept to a
+// bit test and a select.
+template <int MT>
 __global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const Conv3dParams p) {
     __shared__ __attribute__((aligned(16))) float sw[CONV_W_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,67 +57,107 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const 
 
     const long long xbytes = p.x_elems_per_b * 4;
     const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.x + (long long)b * p.x_elems_per_b), 0, (int)(unsigned)(xbytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : xbytes),
+        const_cast<float*>(p.x + (long long)b * p.x_elems_per_b), 0, (int)(unsigned)(xbytes > 0x7FFFFFFFll ? 0x7FFFFFFFll : xbytes),
         0x00020000);
     const int ovox = p.O1 * p.O2 * p.O3;
     const float bias = p.bias[l32];
     float csum = 0.f;
+    // The two waves that share a SIMD are `wave` and `wave + 4` of a block.  Number the waves so that ids below
+    // half the total are the FIRST wave of every SIMD: left-over tiles (tiles_per_b mod waves) then land on
+    // different SIMDs instead of doubling up on some.
+    const int half = p.waves_per_b >> 1;
+    const int wid = (wave < 4) ? (blockIdx.x * 4 + wave) : (half + blockIdx.x * 4 + (wave - 4));
+    const int groups = (p.tiles_per_b + MT - 1) / MT;
 
-    for (int tile = blockIdx.x * (CONV_THREADS / 64) + wave; tile < p.tiles_per_b; tile += p.waves_per_b) {
-        const int v = tile * 32 + l32;
-        const bool vvalid = v < ovox;
-        const int o3 = v % p.O3, o2 = (v / p.O3) % p.O2, o1 = v / (p.O3 * p.O2);
-        f32x16 acc;
+    for (int grp = wid; grp < groups; grp += p.waves_per_b) {
+        int base[MT];
+        unsigned mask[MT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int m = 0; m < MT; ++m) {
+            const int v = (grp * MT + m) * 32 + l32;
+            const bool vvalid = v < ovox;
+            const int o3 = v % p.O3, o2 = (v / p.O3) % p.O2, o1 = v / (p.O3 * p.O2);
+            base[m] = ((((o1 - p.pad) * p.D2 + (o2 - p.pad)) * p.D3 + (o3 - p.pad)) * RC + 4 * h) * 4;
+            // 27-bit tap mask from three 3-bit per-axis masks (bit d = input index o + d - pad is inside the axis)
+            unsigned m1 = 0, m2 = 0, m3 = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                m1 |= ((unsigned)(o1 + d - p.pad) < (unsigned)p.D1) ? (1u << d) : 0u;
+                m2 |= ((unsigned)(o2 + d - p.pad) < (unsigned)p.D2) ? (1u << d) : 0u;
+                m3 |= ((unsigned)(o3 + d - p.pad) < (unsigned)p.D3) ? (1u << d) : 0u;
+            }
+            unsigned mk = 0;
+#pragma unroll
+            for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+                for (int d2 = 0; d2 < 3; ++d2)
+                    mk |= (((m1 >> d1) & (m2 >> d2) & 1u) ? m3 : 0u) << (9 * d1 + 3 * d2);
+            if (!vvalid) mk = 0;
+            mask[m] = mk;
+        }
+        f32x16 acc[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-        auto load_tap = [&](int tap, f32x4(&a)[4]) {
-            const int d1 = tap / 9, d2 = (tap / 3) % 3, d3 = tap % 3;
-            const int i1 = o1 + d1 - p.pad, i2 = o2 + d2 - p.pad, i3 = o3 + d3 - p.pad;
-            const bool ok = vvalid && (unsigned)i1 < (unsigned)p.D1 && (unsigned)i2 < (unsigned)p.D2 &&
-                            (unsigned)i3 < (unsigned)p.D3;
-            // channel offset of this lane half inside an 8-wide k block is 4h; out-of-range -> offset past the SRD
-            const int off = ok ? ((((i1 * p.D2 + i2) * p.D3 + i3) * RC + 4 * h) * 4) : 0x7FFFFF00;
+        f32x4 a0[MT][4], a1[MT][4];   // ping-pong operand registers (taps processed in pairs: no register moves)
+        auto load_tap = [&](int tap, f32x4(&a)[MT][4]) {
+            const int delta = (((tap / 9) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3) * RC * 4;   // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                a[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, off + q * 32, 0, 0));
+            for (int m = 0; m < MT; ++m) {
+                // out-of-range taps read from an offset past the SRD -> 0 ('same' zero padding, ragged last tile)
+                // (the whole offset goes into the VGPR: a raw buffer's range check does not see soffset, and base[m]
+                //  alone is negative on the low borders)
+                const int off = ((mask[m] >> tap) & 1u) ? base[m] + delta : 0x7F000000;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    a[m][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd, off + q * 32, 0, 0));
+            }
         };
-
-        f32x4 a_cur[4], a_nxt[4];
-        load_tap(0, a_cur);
-#pragma unroll 1
-        for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) load_tap(tap + 1, a_nxt);
+        auto mma_tap = [&](int tap, const f32x4(&a)[MT][4]) {
             const float* wt = sw + tap * RC * RC + l32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const float bv = wt[(8 * q + 4 * h + s) * RC];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][s], bv, acc, 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q][s], bv, acc[m], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+        };
+        load_tap(0, a0);
+#pragma unroll 1   // rolled on purpose: unrolled, hipcc hoists all 27x16 LDS weight reads and spills
+        for (int tap = 0; tap < 26; tap += 2) {
+            load_tap(tap + 1, a1);
+            mma_tap(tap, a0);
+            load_tap(tap + 2, a0);
+            mma_tap(tap + 1, a1);
         }
+        mma_tap(26, a0);
 
         // epilogue: C/D map col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4h (voxel inside the tile)
-        float tsum = 0.f;
-        float* yb = p.y + ((long long)b * ovox + (long long)tile * 32) * p.y_cstride + l32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            float o = acc[r] + bias;
-            if (p.relu) o = fmaxf(o, 0.f);
-            if (tile * 32 + row < ovox) {
-                tsum += o;
-                if (l32 < p.cout) yb[(long long)row * p.y_cstride] = o;
+        for (int m = 0; m < MT; ++m) {
+            const int tile = grp * MT + m;
+            float tsum = 0.f;
+            float* yb = p.y + ((long long)b * ovox + (long long)tile * 32) * p.y_cstride + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float o = acc[m][r] + bias;
+                if (p.relu) o = fmaxf(o, 0.f);
+                if (tile * 32 + row < ovox) {
+                    tsum += o;
+                    if (l32 < p.cout) yb[(long long)row * p.y_cstride] = o;
+                }
             }
+            if (p.chan_slab) csum += tsum + __shfl_xor(tsum, 32, 64);
         }
-        if (p.chan_slab) csum += tsum + __shfl_xor(tsum, 32, 64);
     }
-    if (p.chan_slab && lane < 32)
-        p.chan_slab[((long long)b * p.waves_per_b + blockIdx.x * (CONV_THREADS / 64) + wave) * RC + lane] = csum;
+    if (p.chan_slab && lane < 32) p.chan_slab[((long long)b * p.waves_per_b + wid) * RC + lane] = csum;
 }
 
 // ---- stem: Conv3D 1 -> 32, 3x3x3 'same' (network.py:119) ----------------------------------------------------
@@ -329,7 +375,12 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
     p.waves_per_b = waves_per_b;
     p.x_elems_per_b = (long long)D1 * D2 * D3 * RC;
     ProfScope ps(KC_OTHER, st);
-    hipLaunchKernelGGL(conv3d_c32_mfma_kernel, dim3(waves_per_b / (CONV_THREADS / 64), B), dim3(CONV_THREADS), 0, st, p);
+    const dim3 grid(waves_per_b / (CONV_THREADS / 64), B);
+    // two tiles per wave (shared B fragments) once every wave has at least ~3 pairs to chew on
+    if ((long long)p.tiles_per_b >= 6ll * waves_per_b)
+        hipLaunchKernelGGL(conv3d_c32_mfma_kernel<2>, grid, dim3(CONV_THREADS), 0, st, p);
+    else
+        hipLaunchKernelGGL(conv3d_c32_mfma_kernel<1>, grid, dim3(CONV_THREADS), 0, st, p);
     INR_LAUNCH_CHECK();
     return 0;
 }
@@ -337,7 +388,8 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 // number of waves per batch element for the conv kernel: fill the chip once, never more waves than tiles
 int rams_waves_per_b(int B, int ovox) {
     const int tiles = (ovox + 31) / 32;
-    int blocks = (256 + B - 1) / B;                 // ~one block per CU in total
+    int blocks = 256 / B;                           // one 8-wave block per CU (108 KB of LDS each): never more than 256
+                                                    // blocks in total, or a second, nearly empty round doubles the time
     if (blocks < 1) blocks = 1;
     const int max_blocks = (tiles + 7) / 8;
     if (blocks > max_blocks) blocks = max_blocks;
