@@ -83,6 +83,25 @@ def cfg1_quality(inr, steps=2500):
             "fit_plus_recon_seconds": dt, "train_voxels_per_s": lr.size * steps / dt}
 
 
+def rams_leg(batch=25, reps=3):
+    """Config 3 (multi-image CNN): RAMS(3,32,3,9,8,12) forward on a synthetic (25,128,128,9) uint16-range batch = the 25
+    random 9-acquisition subsets of one case (multi-image-super-resolution/master.py:43-52) as one batched call."""
+    from mri_super_resolution_amd import rams
+    model = rams.RAMS(seed=0)
+    x = torch.from_numpy((np.random.default_rng(0).random((batch, 128, 128, 9)) * 60000).astype(np.float32)).cuda()
+    rams.predict_tensor(model, x)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rams.predict_tensor(model, x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"config": f"RAMS(3,32,3,9,8,12) predict_tensor, batch {batch} x (128,128,9) -> (384,384), random weights",
+            "ms_per_stack": dt / batch * 1e3, "stacks_per_s": batch / dt, "output_voxels_per_s": batch * 384 * 384 / dt,
+            "tflops": 265.0e9 * batch / dt / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
+            "flop_per_stack": 265.0e9}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +223,7 @@ def main():
         del rec
         fitter.release_workspace()
         out["quality"] = cfg1_quality(inr)
+        out["rams"] = rams_leg()
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, B_np, vol)
         out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-        f32x4 a0[MT][4], a1[MT][4];   // ping-pong operand registers (taps processed in pairs: no register moves)
+        f32x4 a0[MT][4], a1[MT][4];   // rotating operand registers (no register moves between taps)
         auto load_tap = [&](int tap, f32x4(&a)[MT][4]) {
             const int delta = (((tap / 9) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3) * RC * 4;   // wave-uniform
 #pragma unroll
@@ -128,15 +128,23 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const 
                 }
             }
         };
+        // operands are fetched two taps ahead of their MFMAs (three rotating register sets, 27 = 9 x 3 taps)
+        f32x4 a2[MT][4];
         load_tap(0, a0);
+        load_tap(1, a1);
 #pragma unroll 1   // rolled on purpose: unrolled, hipcc hoists all 27x16 LDS weight reads and spills
-        for (int tap = 0; tap < 26; tap += 2) {
-            load_tap(tap + 1, a1);
+        for (int tap = 0; tap < 24; tap += 3) {
+            load_tap(tap + 2, a2);
             mma_tap(tap, a0);
-            load_tap(tap + 2, a0);
+            load_tap(tap + 3, a0);
             mma_tap(tap + 1, a1);
+            load_tap(tap + 4, a1);
+            mma_tap(tap + 2, a2);
         }
-        mma_tap(26, a0);
+        load_tap(26, a2);
+        mma_tap(24, a0);
+        mma_tap(25, a1);
+        mma_tap(26, a2);
 
         // epilogue: C/D map col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4h (voxel inside the tile)
 #pragma unroll
