@@ -102,6 +102,11 @@ long long rams_param_floats(const inr_rams_desc_t* d);
 size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W);
 int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
                       int clip_round, float* ws, hipStream_t st);
+bool small_path_ok(const inr_siren_desc_t* d, int64_t n);
+size_t small_workspace_floats(const inr_siren_desc_t* d, int64_t n, long long P);
+int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long long* b_off, long long P, float* params,
+                   float* grads, float* m, float* v, const float* x, const float* target, const float* weight, int64_t n,
+                   int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
 extern int g_force_generic;
 extern unsigned long long* g_stamps;
 
@@ -487,6 +492,10 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     if (mse > scratch) scratch = mse;
     c.scratch_b = round_up(scratch * sizeof(float), 256);
     c.total = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
+    if (small_path_ok(d, n)) {   // the fused small-network step carves the same workspace differently
+        const size_t small = round_up(small_workspace_floats(d, n, L.total) * sizeof(float), 256);
+        if (small > c.total) c.total = small;
+    }
     return c;
 }
 
@@ -523,6 +532,20 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
     float* scratch = (float*)((char*)gy + c.out_b);
     float* loss_sink = scratch;  // overwritten later in the step; only used when losses == nullptr
     const int H = desc->hidden_features, O = desc->out_features, head = L.n_sine;
+
+    if (small_path_ok(desc, n) && !g_force_generic) {
+        // master.py regime (small network, few thousand rows): one fused forward+backward launch + one reduce/Adam
+        // launch per step instead of ~45 layer-wise launches (csrc/siren_small.hip)
+        long long w_off[32], b_off[32];
+        for (int l = 0; l <= L.n_sine; ++l) { w_off[l] = L.w_off[l]; b_off[l] = L.b_off[l]; }
+        for (int it = 0; it < n_steps; ++it) {
+            if (int rc = small_fit_step(desc, w_off, b_off, L.total, params, grads, m, v, x, target, weight, n,
+                                        first_step + it, lr, beta1, beta2, eps, losses ? losses + it : nullptr,
+                                        (float*)workspace, st))
+                return rc;
+        }
+        return 0;
+    }
 
     for (int it = 0; it < n_steps; ++it) {
         // forward with stash (SRDWI.py:58-59 per layer; dact = omega*cos(.) replaces autograd's saved z)

@@ -475,3 +475,29 @@ def test_pn_phase_as_in_superresdwi(golden):
         assert O.rel_l2(host(out), rout.detach().numpy()) < T1
         for (n, a), (_, b) in zip(pn.named_parameters(), rpn.named_parameters()):
             assert O.rel_l2(host(a.grad), b.grad.numpy()) < 5e-5, n
+
+
+# ------------------------------------------------------------------ small-network fused step (master.py regime) ------
+@pytest.mark.parametrize("n,fin,hidden,layers", [(3600, 2, 64, 6), (1000, 3, 32, 2), (77, 5, 64, 1), (4096, 2, 64, 3)])
+def test_small_fused_step_equals_layerwise_path(n, fin, hidden, layers):
+    """siren_small.hip (2 launches/step) against the layer-by-layer kernels on the same data: same arithmetic up to
+    the order of the row-wise gradient sums."""
+    from mri_super_resolution_amd import _lib
+    rng = np.random.default_rng(n)
+    x = dev(rng.random((n, fin)) * 2 - 1)
+    t = dev(rng.random((n, 1)))
+    w = dev((rng.random((n, 1)) > 0.3).astype(np.float32))
+    out = {}
+    for force_generic in (1, 0):
+        _lib.lib().inr_debug_set(0, force_generic)
+        try:
+            torch.manual_seed(7)
+            net = inr.Siren(fin, hidden, layers, 1).cuda()
+            fitter = inr.SirenFitter(net, lr=3e-4)
+            losses = host(fitter.step(x, t, n_steps=8, weight=w))
+            out[force_generic] = (losses, host(fitter.flat).copy(), host(fitter.grads).copy())
+        finally:
+            _lib.lib().inr_debug_set(0, 0)
+    assert np.allclose(out[0][0], out[1][0], rtol=2e-5)
+    assert O.rel_l2(out[0][2], out[1][2]) < 2e-5            # gradients of the last step
+    assert O.rel_l2(out[0][1], out[1][1]) < 2e-5            # parameters after 8 Adam steps
