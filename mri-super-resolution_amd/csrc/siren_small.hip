@@ -53,15 +53,29 @@ __global__ void __launch_bounds__(256) siren_small_step_kernel(const SmallParams
     float* slab = p.slabs + (long long)gwave * p.P;
     const long long NH = (long long)p.N * H;
 
-    auto load_weights = [&](int l, int K) {   // W_l [H][K] -> ldsW [H][K+4]; whole block, fenced by barriers
+    // Hidden-layer weights W_l [H][H] travel global -> registers -> ldsW [H][H+4] in two halves so the global latency
+    // hides behind the previous layer's arithmetic: fetch_weights(l) is issued a layer early, commit_weights() (whole
+    // block, fenced by barriers) makes them the current LDS image.
+    constexpr int WQ = (H * H / 4) / 256;   // float4 per thread
+    f32x4 wreg[WQ];
+    auto fetch_weights = [&](int l) {
+        const f32x4* W = reinterpret_cast<const f32x4*>(p.params + p.w_off[l]);
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) wreg[i] = W[tid + 256 * i];
+    };
+    auto commit_weights = [&]() {
         __syncthreads();
-        const float* W = p.params + p.w_off[l];
-        for (int i = tid; i < H * K; i += 256) ldsW[(i / K) * (K + 4) + (i % K)] = W[i];
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<f32x4*>(ldsW + (f / (H / 4)) * LDS_STRIDE + (f % (H / 4)) * 4) = wreg[i];
+        }
         __syncthreads();
     };
 
     // ------------------------------------------------ forward ------------------------------------------------
     f32x16 acc[CT], dlast[CT];
+    if (p.S > 1) fetch_weights(1);
     {   // layer 0: z0 = x W0^T + b0, K = F (k = 2*kp + hh, zero beyond F); operands straight from global memory
         const float* W0 = p.params + p.w_off[0];
 #pragma unroll
@@ -80,7 +94,8 @@ __global__ void __launch_bounds__(256) siren_small_step_kernel(const SmallParams
     }
     for (int l = 0; l < p.S; ++l) {
         if (l > 0) {   // z_l = a_l W_l^T: A from the wave's stage (k-contiguous b128), B = W_l rows (k-contiguous b128)
-            load_weights(l, H);
+            commit_weights();
+            if (l + 1 < p.S) fetch_weights(l + 1);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -173,8 +188,32 @@ __global__ void __launch_bounds__(256) siren_small_step_kernel(const SmallParams
         if (hh == 0) slab[p.w_off[p.S] + j] = gw;
     }
 
+    // (ldsW still holds W_{S-1} from the forward pass: the first backward layer needs no reload)
+    // Order inside a layer is chosen for a single wave per SIMD (nothing else hides latency): the global reads this
+    // layer needs later (its input a_l, the layer below's d_{l-1}, the next weights) are issued first, then the
+    // input-grad MFMAs (LDS only) run while they are in flight, and the weight-grad contraction comes last.
     for (int l = p.S - 1; l >= 0; --l) {
         const int K = (l == 0) ? p.F : H;
+        f32x4 a_pref[(32 * H / 4) / 64];
+        f32x16 d_pref[CT];
+        if (l > 0) {
+            const float* a_in = p.acts + (long long)l * NH;
+#pragma unroll
+            for (int it = 0; it < (32 * H / 4) / 64; ++it) {
+                const int f = it * 64 + lane, rr = f / (H / 4), c4 = (f % (H / 4)) * 4;
+                a_pref[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (r0 + rr < p.N) a_pref[it] = *reinterpret_cast<const f32x4*>(a_in + (long long)(r0 + rr) * H + c4);
+            }
+            const float* d_in = p.dacts + (long long)(l - 1) * NH;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = acc_row(r, hh);
+                    d_pref[ct][r] = (r0 + i < p.N) ? d_in[(long long)(r0 + i) * H + ct * 32 + l32] : 0.f;
+                }
+        }
+        if (l > 1) fetch_weights(l - 1);     // committed after this layer's input grad
         // bias gradient + dz into its operand image
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -188,17 +227,34 @@ __global__ void __launch_bounds__(256) siren_small_step_kernel(const SmallParams
             gb += __shfl_xor(gb, 32, 64);
             if (hh == 0) slab[p.b_off[l] + j] = gb;
         }
-        if (l > 0) {   // a_l (input of layer l) back from the scratch into the stage: 32 rows x H floats, float4 per lane
-            const float* a_in = p.acts + (long long)l * NH;
+        if (l > 0) {   // da_l = dz_l W_l, then dz_{l-1} = da_l * d_{l-1}  (dz_l itself lives on in stageD for the weight grad)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < H / 8; ++kb) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(stageD + l32 * LDS_STRIDE + 8 * kb + 4 * hh);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float* wrow = ldsW + (8 * kb + 4 * hh + s) * LDS_STRIDE + l32;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], wrow[ct * 32], acc[ct], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dz[ct][r] = acc[ct][r] * d_pref[ct][r];
+            // a_l into the stage: 32 rows x H floats, one float4 per lane and pass
 #pragma unroll
             for (int it = 0; it < (32 * H / 4) / 64; ++it) {
                 const int f = it * 64 + lane, rr = f / (H / 4), c4 = (f % (H / 4)) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (r0 + rr < p.N) v = *reinterpret_cast<const f32x4*>(a_in + (long long)(r0 + rr) * H + c4);
-                *reinterpret_cast<f32x4*>(stageA + rr * LDS_STRIDE + c4) = v;
+                *reinterpret_cast<f32x4*>(stageA + rr * LDS_STRIDE + c4) = a_pref[it];
             }
         }
-        // weight gradient: gW_l[j][k] = sum_rows dz[row][j] * a_l[row][k]   (contraction over the wave's 32 rows)
+        // weight gradient: gW_l[j][k] = sum_rows dz_l[row][j] * a_l[row][k]   (contraction over the wave's 32 rows)
         const int KT = (K + 31) / 32;
         for (int ht = 0; ht < CT; ++ht) {
             for (int kt = 0; kt < KT; ++kt) {
@@ -227,40 +283,13 @@ __global__ void __launch_bounds__(256) siren_small_step_kernel(const SmallParams
                 }
             }
         }
-        if (l > 0) {   // da_l = dz_l W_l, then dz_{l-1} = da_l * d_{l-1}
-            load_weights(l, H);
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < H / 8; ++kb) {
-                const f32x4 fa = *reinterpret_cast<const f32x4*>(stageD + l32 * LDS_STRIDE + 8 * kb + 4 * hh);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float* wrow = ldsW + (8 * kb + 4 * hh + s) * LDS_STRIDE + l32;
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], wrow[ct * 32], acc[ct], 0, 0, 0);
-                }
-            }
-            const float* d_in = p.dacts + (long long)(l - 1) * NH;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int j = ct * 32 + l32;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = acc_row(r, hh);
-                    const float dv = (r0 + i < p.N) ? d_in[(long long)(r0 + i) * H + j] : 0.f;
-                    dz[ct][r] = acc[ct][r] * dv;
-                }
-            }
-        }
+        if (l > 1) commit_weights();
     }
 }
 
-// grads[i] = sum over wave slabs (fixed order); Adam update (torch single-tensor formulation); block 0 also
-// finishes the loss.  One thread per parameter.
+// grads[i] = sum over wave slabs (fixed order); Adam update (torch single-tensor formulation); block 0 also finishes
+// the loss.  A block owns 64 consecutive parameters; its 4 waves each sum a quarter of the slabs (coalesced 256-B
+// reads), the quarters are combined through LDS in a fixed order.
 __global__ void __launch_bounds__(256) small_reduce_adam_kernel(float* __restrict__ params, float* __restrict__ grads,
                                                                 float* __restrict__ m, float* __restrict__ v,
                                                                 const float* __restrict__ slabs, int nslabs, long long P,
@@ -268,16 +297,23 @@ __global__ void __launch_bounds__(256) small_reduce_adam_kernel(float* __restric
                                                                 float step_size, float bc2_sqrt, float eps,
                                                                 float* __restrict__ loss_out,
                                                                 const float* __restrict__ loss_partial, float inv_count) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[4][64];
+    __shared__ float red[256];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f;
     if (i < P) {
-        float a0 = 0.f, a1 = 0.f;
-        int s = 0;
-        for (; s + 1 < nslabs; s += 2) {
+        int s = q;
+        for (; s + 4 < nslabs; s += 8) {
             a0 += slabs[(long long)s * P + i];
-            a1 += slabs[(long long)(s + 1) * P + i];
+            a1 += slabs[(long long)(s + 4) * P + i];
         }
         if (s < nslabs) a0 += slabs[(long long)s * P + i];
-        const float gi = a0 + a1;
+    }
+    part[q][lane] = a0 + a1;
+    __syncthreads();
+    if (q == 0 && i < P) {
+        const float gi = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
         grads[i] = gi;
         const float mi = fmaf(gi - m[i], one_minus_b1, m[i]);
         const float vi = fmaf(one_minus_b2 * gi, gi, v[i] * b2);
@@ -287,7 +323,6 @@ __global__ void __launch_bounds__(256) small_reduce_adam_kernel(float* __restric
         params[i] = params[i] - step_size * (mi / denom);
     }
     if (blockIdx.x == 0 && loss_out) {
-        __shared__ float red[256];
         float acc = 0.f;
         for (int k = threadIdx.x; k < nslabs; k += 256) acc += loss_partial[k];
         red[threadIdx.x] = acc;
@@ -338,7 +373,7 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
         hipLaunchKernelGGL(siren_small_step_kernel<32>, dim3(blocks), dim3(256), 0, st, p);
     INR_LAUNCH_CHECK();
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-    hipLaunchKernelGGL(small_reduce_adam_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, params, grads, m, v,
+    hipLaunchKernelGGL(small_reduce_adam_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, params, grads, m, v,
                        p.slabs, nwaves, P, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1),
                        (float)sqrt(bc2), (float)eps, loss_out, p.loss_partial, p.inv_count);
     INR_LAUNCH_CHECK();
