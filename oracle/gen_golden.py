@@ -67,6 +67,7 @@ def main():
     hr = (vol[:, :, 11] / vol[:, :, 11].max()).astype(np.float32)
     lr = np.ascontiguousarray(hr[::2, ::2])
     save("pat07_slice11.npz", hr=hr, lr=lr, vol_shape=np.array(vol.shape), vol_max=np.float32(vol.max()))
+    save("pat07_volume.npz", vol=np.ascontiguousarray(vol.astype(np.float32)))   # config 2 input (whole volume)
 
     # ---- dataset flattening (a-2) + Fourier features (a-3) -----------------------------
     ds = SRDWI.ImageFitting_set([lr.astype(np.float64)])

@@ -76,3 +76,22 @@ def test_run_volumes_single_process():
     assert [int(r["job"]) for r in recs] == [0, 1, 2]
     assert [int(r["n_coords"]) for r in recs] == [4 * 4 * 3, 4 * 4 * 2, 4 * 4 * 4]
     assert all(np.isfinite(r["final_loss"]) for r in recs)
+
+
+def test_fit_volume_cfg2_short(golden):
+    """Config 2 input (whole pat07 volume): the first steps of the 3-D fit track the CPU port (kept short: the port
+    needs seconds per step at N = 114,688)."""
+    vol = golden("pat07_volume.npz")["vol"]
+    assert vol.shape == (128, 128, 28)
+    res = drivers.fit_volume(vol, steps=6, seed=0)
+    assert res["n_coords"] == 64 * 64 * 28 and tuple(res["recon"].shape) == (256, 256, 28)
+    lr = np.ascontiguousarray((vol / vol.max())[::2, ::2, :])
+    B = torch.from_numpy(P.fourier_matrix(3))
+    torch.manual_seed(0)
+    ref = P.PortSiren(256, 512, 3, 1)
+    x = P.port_input_mapping(P.port_mgrid(lr.shape), B)
+    losses, _ = P.port_fit(ref, x, torch.from_numpy(lr.reshape(-1, 1)), 6, lr=1e-4)
+    assert res["final_loss"] == pytest.approx(losses[-1], rel=1e-3)
+    want = P.port_reconstruct(ref, (128, 128, 28), B)
+    got = drivers.reconstruct(res["model"], (128, 128, 28), res["B"]).cpu().numpy()
+    assert O.rel_l2(got, want) < 1e-4
