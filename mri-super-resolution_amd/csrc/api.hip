@@ -108,6 +108,7 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
                    float* grads, float* m, float* v, const float* x, const float* target, const float* weight, int64_t n,
                    int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
 extern int g_force_generic;
+extern int g_mfma16;
 extern unsigned long long* g_stamps;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
@@ -697,6 +698,7 @@ int inr_debug_set_ptr(int key, void* ptr) {
 
 int inr_debug_set(int key, int value) {
     if (key == 0) { g_force_generic = value; return 0; }
+    if (key == 1) { g_mfma16 = value; return 0; }
     return INR_E_INVALID;
 }
 

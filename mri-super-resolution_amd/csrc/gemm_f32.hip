@@ -369,6 +369,10 @@ __device__ __forceinline__ EpiAddr epi_addr(const GemmParams& p, int m0, int n0,
     return a;
 }
 
+template <int EPI, int SUBS>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __restrict__ sub, const EpiAddr& a,
+                                              const f32x4 (&mulreg)[16], int n0, int wn, int lane, int slab_row);
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x16 (&acc)[2][2], float* __restrict__ sub,
                                                 const EpiAddr& a, const f32x4 (&mulreg)[16], int n0, int wn, int lane,
@@ -381,18 +385,26 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 sub[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + l32] = acc[i][j][r];
+    epilogue_rows<EPI, 64>(p, sub, a, mulreg, n0, wn, lane, slab_row);
+}
+
+// second half of the staged epilogue: the wave's 64x64 sub-tile sits in `sub` as [row][SUBS]; lane's q-th float4 is
+// row 4q + lane/16, columns 4*(lane%16) .. +3
+template <int EPI, int SUBS>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __restrict__ sub, const EpiAddr& a,
+                                              const f32x4 (&mulreg)[16], int n0, int wn, int lane, int slab_row) {
     INR_STAMP(5);
     f32x4 bias = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_SINE || EPI == EPI_SINE_STASH || EPI == EPI_TANH || EPI == EPI_TANH_STASH) {
         const int col = n0 + wn * 64 + (lane & 15) * 4;
         if (p.bias && col < p.N) bias = *reinterpret_cast<const f32x4*>(p.bias + col);
     }
-    const float* rd = sub + (lane >> 4) * 64 + (lane & 15) * 4;
+    const float* rd = sub + (lane >> 4) * SUBS + (lane & 15) * 4;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     float zmax = 0.f;   // largest |omega*z| seen by this lane (sine epilogues)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 4 * SUBS);
         const int so = q * a.row_step;
         if (q == 8) INR_STAMP(6);
         if (EPI == EPI_SINE || EPI == EPI_SINE_STASH) {
@@ -422,7 +434,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, const f32x1
         if (__builtin_expect(__any(!(zmax < INR_SINCOS_FAST_LIMIT)), 0)) {
 #pragma unroll 1
             for (int q = 0; q < 16; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 256);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 4 * SUBS);
                 const f32x4 z = p.omega * (v + bias);
                 f32x4 sv, cv;
 #pragma unroll 1
@@ -581,8 +593,206 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmPa
     INR_STAMP(4);
 }
 
+// =====================================================================================================
+// pipelined kernel on v_mfma_f32_16x16x4_f32  (same tiles, same staging; 32-cycle MFMAs)
+// =====================================================================================================
+// A register-only loop of the 16x16x4 form runs 6 % faster than 32x32x2 on this part (147-150 vs 138-142 TFLOP/s,
+// tools/mfma_rate.hip) and offers VALU/LDS instructions an issue slot every 32 instead of every 64 cycles.
+// Wave tile 64x64 = 4x4 accumulators of 16x16; inside a 16-wide k block lane group g = lane/16 consumes
+// k = 4g..4g+3 for both operands (again a fixed permutation of the k-sum; one b128 read feeds four MFMAs).
+// r/n-contiguous LDS images get a row stride of 132 floats so the four lane groups of a ds_read_b32 hit four bank
+// quarters; the epilogue stage uses a row stride of 68 for the same reason.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int LDM16 = BM + 4;
+
+template <bool KC>
+struct TileSize16 {
+    static constexpr int floats = KC ? BM * LDK : BK * LDM16;
+};
+
+template <bool KCONTIG>
+__device__ __forceinline__ void store_tile16(float* __restrict__ S, const f32x4 (&reg)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KCONTIG) {
+            const int r = (tid >> 3) + 32 * i, k = (tid & 7) * 4;
+            *reinterpret_cast<f32x4*>(S + r * LDK + k) = reg[i];
+        } else {
+            const int k = (tid >> 5) + 8 * i, r = (tid & 31) * 4;
+            *reinterpret_cast<f32x4*>(S + k * LDM16 + r) = reg[i];
+        }
+    }
+}
+
+struct Frags16 {
+    f32x4 a[4], b[4];
+};
+
+// fragment of 4 k-values (k = kb*16 + 4g + 0..3) for row `r`
+template <bool KCONTIG>
+__device__ __forceinline__ f32x4 read_frag16(const float* __restrict__ S, int r, int kb, int g) {
+    if (KCONTIG) {
+        return *reinterpret_cast<const f32x4*>(S + r * LDK + kb * 16 + 4 * g);
+    } else {
+        const float* p = S + (kb * 16 + 4 * g) * LDM16 + r;
+        f32x4 v;
+        v[0] = p[0];
+        v[1] = p[LDM16];
+        v[2] = p[2 * LDM16];
+        v[3] = p[3 * LDM16];
+        return v;
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void read_frags16(Frags16& f, const float* __restrict__ sA, const float* __restrict__ sB,
+                                             int arow, int brow, int kb, int g) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = read_frag16<A_KC>(sA, arow + i * 16, kb, g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f.b[j] = read_frag16<B_KC>(sB, brow + j * 16, kb, g);
+}
+
+// MFMAs of k sub-steps [S0, S1) of one 16-wide k block
+template <int S0, int S1>
+__device__ __forceinline__ void mfma_block16(f32x4v (&acc)[4][4], const Frags16& f) {
+#pragma unroll
+    for (int s = S0; s < S1; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+}
+
+// NM MFMAs with NR LDS reads and NX other memory instructions (mask XMASK) spread evenly between them
+template <int NM, int NR, int NX, int XMASK, int I>
+__device__ __forceinline__ void sched_interleave_n() {
+    if constexpr (I < NM) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int r = (I + 1) * NR / NM - I * NR / NM;
+        if constexpr (r > 0) __builtin_amdgcn_sched_group_barrier(0x100, r, 0);
+        constexpr int x = (I + 1) * NX / NM - I * NX / NM;
+        if constexpr (x > 0) __builtin_amdgcn_sched_group_barrier(XMASK, x, 0);
+        sched_interleave_n<NM, NR, NX, XMASK, I + 1>();
+    }
+}
+
+constexpr int SUB16 = 68;                       // epilogue stage row stride (floats)
+constexpr int STAGE16_FLOATS = 4 * 64 * SUB16;  // four waves x 64 rows
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const GemmParams p) {
+    constexpr int STAGE = TileSize16<A_KC>::floats + TileSize16<B_KC>::floats;
+    constexpr int BOFF = TileSize16<A_KC>::floats;
+    constexpr int SMEM = (2 * STAGE > STAGE16_FLOATS) ? 2 * STAGE : STAGE16_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    constexpr int NR = (A_KC ? 4 : 16) + (B_KC ? 4 : 16);  // LDS read instructions per 16-wide k block
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, l16 = lane & 15;
+    const TileCoord tc = decode_block(p);
+    const int m0 = tc.tile_m * BM, n0 = tc.tile_n * BN;
+    const int k_begin = tc.split * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+    const int ktiles = (k_end - k_begin + BK - 1) / BK;
+    const long long a_first = A_KC ? ((long long)m0 * p.lda + k_begin) : ((long long)k_begin * p.lda + m0);
+    const long long b_first = B_KC ? ((long long)n0 * p.ldb + k_begin) : ((long long)k_begin * p.ldb + n0);
+    const long long a_span = A_KC ? (long long)BM * p.lda : (long long)(k_end - k_begin) * p.lda;
+    const long long b_span = B_KC ? (long long)BN * p.ldb : (long long)(k_end - k_begin) * p.ldb;
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(p.A + a_first, min(p.a_elems - a_first, a_span) * 4);
+    const __amdgpu_buffer_rsrc_t srdB = make_srd(p.B + b_first, min(p.b_elems - b_first, b_span) * 4);
+    const int a_step = (A_KC ? BK : BK * p.lda) * 4;
+    const int b_step = (B_KC ? BK : BK * p.ldb) * 4;
+    int va[4], vb[4];
+    tile_voffsets<A_KC>(va, p.lda, tid);
+    tile_voffsets<B_KC>(vb, p.ldb, tid);
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const int arow = wm * 64 + l16, brow = wn * 64 + l16;
+    f32x4 ra[4], rb[4];
+    Frags16 f0, f1;
+
+    if (ktiles > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = buf_load4(srdA, va[i], 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = buf_load4(srdB, vb[i], 0);
+        store_tile16<A_KC>(smem, ra, tid);
+        store_tile16<B_KC>(smem + BOFF, rb, tid);
+    }
+    __syncthreads();
+    if (ktiles > 0) read_frags16<A_KC, B_KC>(f0, smem, smem + BOFF, arow, brow, 0, g);
+
+    int a_off = 0, b_off = 0;
+    for (int t = 0; t + 1 < ktiles; ++t) {
+        const float* cA = smem + (t & 1) * STAGE;
+        const float* cB = cA + BOFF;
+        float* nA = smem + ((t & 1) ^ 1) * STAGE;
+        float* nB = nA + BOFF;
+        a_off += a_step;
+        b_off += b_step;
+        // k block 0 (64 MFMAs): prefetch the fragments of k block 1, issue the next K-tile's global loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = buf_load4(srdA, va[i], a_off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = buf_load4(srdB, vb[i], b_off);
+        read_frags16<A_KC, B_KC>(f1, cA, cB, arow, brow, 1, g);
+        mfma_block16<0, 4>(acc, f0);
+        sched_interleave_n<64, NR, 8, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        // first half of k block 1: park the next K-tile in the other LDS buffer
+        store_tile16<A_KC>(nA, ra, tid);
+        store_tile16<B_KC>(nB, rb, tid);
+        mfma_block16<0, 2>(acc, f1);
+        sched_interleave_n<32, 0, 8, 0x200, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // second half: operands already in registers; fetch k block 0 of the next K-tile
+        read_frags16<A_KC, B_KC>(f0, nA, nB, arow, brow, 0, g);
+        mfma_block16<2, 4>(acc, f1);
+        sched_interleave_n<32, NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const EpiAddr ea = epi_addr<EPI>(p, m0, n0, wm, wn, lane, tc.split);
+    f32x4 mulreg[16];
+    if (EPI == EPI_MUL) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mulreg[q] = buf_load4(ea.srdMul, ea.voff, q * ea.row_step);
+    }
+    if (ktiles > 0) {
+        const float* cA = smem + ((ktiles - 1) & 1) * STAGE;
+        const float* cB = cA + BOFF;
+        read_frags16<A_KC, B_KC>(f1, cA, cB, arow, brow, 1, g);
+        mfma_block16<0, 4>(acc, f0);
+        sched_interleave_n<64, NR, 0, 0x020, 0>();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block16<0, 4>(acc, f1);
+    }
+
+    __syncthreads();  // every wave is done with the operand tiles: LDS becomes the epilogue staging area
+    // C/D map of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
+    float* sub = smem + wave * (64 * SUB16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sub[(i * 16 + 4 * g + r) * SUB16 + j * 16 + l16] = acc[i][j][r];
+    epilogue_rows<EPI, SUB16>(p, sub, ea, mulreg, n0, wn, lane, tc.tile_m * 2 + wm);
+}
+
+
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
+int g_mfma16 = 1;         // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
 
 // ---- host-side launch --------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
@@ -601,7 +811,9 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
                       (a_span + (long long)BK * p.lda) * 4 < (1ll << 31) &&
                       (b_span + (long long)BK * p.ldb) * 4 < (1ll << 31);
     if (used_fast) *used_fast = fast;
-    if (fast)
+    if (fast && g_mfma16)
+        hipLaunchKernelGGL((gemm_f32_pipe16_kernel<A_KC, B_KC, EPI>), grid, block, 0, stream, p);
+    else if (fast)
         hipLaunchKernelGGL((gemm_f32_pipe_kernel<A_KC, B_KC, EPI>), grid, block, 0, stream, p);
     else if (vec)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI, true>), grid, block, 0, stream, p);
