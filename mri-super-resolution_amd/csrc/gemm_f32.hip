@@ -1,33 +1,34 @@
 // fp32 MFMA GEMM with fused epilogues -- the three dense contractions of the SIREN fit step.
 //
 //   forward   (K3, SRDWI.py:58-59)  act = sin(w*(x W^T + b)), dact = w*cos(...)   A k-contig, B k-contig
-//   input-grad (K6)                 dz_prev = (dz W) * dact_prev                  A k-contig, B n-contig
+//   input-grad (K6)                 dz_prev = (dz W) * dact_prev  (+ bias-grad sums) A k-contig, B n-contig
 //   param-grad (K6)                 gW = dz^T x  (split over rows, slabs)         A m-contig, B n-contig
 //
-// 128x128x32 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 sub-tile as 2x2
-// v_mfma_f32_32x32x2_f32 accumulators (exact fp32 products, fp32 accumulate -- the only MFMA form on
-// gfx950 that meets the 1e-5 parity tier; peak 157.3 TFLOP/s).
-// LDS images: k-contiguous operands as [rows][BK+4] (row stride 9 x 16 B: ds_read_b128 of 16 rows
-// hits 16 distinct 16-B slots), m/n-contiguous operands as [BK][128] read with ds_read_b32.
-// Within an 8-wide k block lane-half h consumes k = 4h..4h+3 for BOTH operands (a fixed permutation
-// of the k-sum, so one b128 read feeds four MFMAs).
-// blockIdx is remapped so that consecutive logical tiles (which share an A row-panel) land on the
-// same XCD and reuse it from that XCD's L2.
+// 128x128x32 block tile, 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 sub-tile.  Exact fp32 products
+// with fp32 accumulation (f32-input MFMA): the only operand type on gfx950 that meets the 1e-5 parity tier; dense
+// peak 157.3 TFLOP/s.  Three kernels share the tile geometry, the staging scheme and the epilogue:
+//   gemm_f32_pipe16_kernel -- DEFAULT.  v_mfma_f32_16x16x4_f32, 4x4 accumulators per wave; within a 16-wide k block
+//       lane group g = lane/16 consumes k = 4g..4g+3 for BOTH operands (a fixed permutation of the k-sum, so one
+//       b128 LDS read feeds four MFMAs).  Operands arrive through buffer loads (per-block SRD: rows past the matrix
+//       end read as 0, no exec-mask branches) into registers, fragments are prefetched one k block ahead into a
+//       second register set, the next K-tile's global loads / LDS stores are interleaved between the MFMAs with
+//       sched_group_barrier, and the single barrier per K-step sits in the middle of the second k block so the MFMAs
+//       behind it already hold their operands.  Epilogue: the accumulators are parked in the (idle) operand LDS and
+//       read back row-contiguous -> float4 buffer stores, hardware sin/cos on an FMA-reduced argument, dact fetched
+//       under the last K-tile, bias-gradient column sums.
+//   gemm_f32_pipe_kernel   -- the same structure on v_mfma_f32_32x32x2_f32 (2x2 accumulators, k = 4h..4h+3 per
+//       8-block).  Kept for A/B (inr_debug_set(1, 0)): 5-7 % slower (tools/gemm_ab.py).
+//   gemm_f32_kernel        -- generic fallback (any shape/alignment: scalar guarded loads), 32x32x2, plain loop.
+// blockIdx is remapped so that consecutive logical tiles (which share an A row-panel) land on the same XCD.
 //
-// Two kernels share the tile layout and the epilogue:
-//   gemm_f32_pipe_kernel  -- the hot one.  Operands come through buffer loads (per-block SRD: rows past
-//       the matrix end read as 0, no exec-mask branches), fragments are prefetched one 8-wide k block
-//       ahead into a second register set, the next tile's global loads / LDS stores are interleaved
-//       between the MFMAs with sched_group_barrier, and the single barrier per K-step sits between the
-//       third and fourth k block so the MFMAs that follow it already have their operands in registers.
-//       Measured facts that shaped it (s_memtime stamps, tools/stamp_timeline.py; tools/mfma_rate.hip):
-//       the f32 MFMA shares the f32 VALU lanes -- a co-resident wave's VALU instructions issue about one
-//       per MFMA boundary, so an epilogue that overlaps the other block's main loop is stretched ~4x and
-//       every VALU instruction removed from it counts (hence v_sin/v_cos on an FMA-reduced argument and
-//       16-byte staged stores); a bare register-only 32x32x2 loop reaches 138-142 TFLOP/s on this part,
-//       which is the practical ceiling of the main loop (param-grad runs at 140-142).
-//       Start-time staggering of co-resident blocks and s_setprio in either direction were tried: no effect.
-//   gemm_f32_kernel       -- generic fallback (any shape/alignment: scalar guarded loads), same numerics.
+// Measured facts that shaped it (s_memtime stamps: tools/stamp_timeline.py; tools/mfma_rate.hip, tools/gemm_ab.py):
+//   * the f32 MFMA shares the f32 VALU lanes: a co-resident wave's VALU instructions issue about once per MFMA
+//     boundary, so an epilogue that overlaps the other block's main loop is stretched ~4x and every VALU instruction
+//     in it counts (v_sin/v_cos on a reduced argument, 16-byte staged stores, fused bias sums);
+//   * register-only loops reach 138-142 TFLOP/s with 32x32x2 and 147-150 with 16x16x4 on this part; in the full
+//     kernel 16x16x4 gives fwd 136 / input-grad 141 / param-grad 147 (32x32x2: 130 / 131 / 141);
+//   * tried without effect: start-time staggering of co-resident blocks or of the whole first wave, s_setprio in
+//     either direction; tried and slower: a persistent grid with cross-tile operand prefetch (-4 %).
 #include "common.h"
 
 namespace inr {
