@@ -187,6 +187,14 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
                   int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps,
                   float* losses, void* workspace, size_t workspace_bytes, void* stream);
 
+/* (e) one fit split over several GPUs: forward + loss + backward of THIS rank's row shard, no optimizer.
+ * The mean of the loss runs over count_total elements (0 = n*out_features, i.e. an unsplit fit), so gradients and
+ * losses of the shards add up to the full-batch step: all-reduce(sum) `grads` (flat, inr_siren_param_count floats)
+ * and `loss`, then call inr_adam_step on every rank.  Workspace: inr_siren_fit_workspace_bytes(desc, n). */
+int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
+                        const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a-12: end-of-fit metrics on the device (fp64 accumulation, fixed-order reductions) -----------------
  * workspace for all three image metrics: inr_metric_workspace_bytes(n_images).
  * inr_psnr:   out[b] (double) = 10*log10(data_range^2 / mean((x_b - y_b)^2)); x, y are [n_images][per_image] fp32.

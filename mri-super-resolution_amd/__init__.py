@@ -11,10 +11,10 @@ dist.py (fit partitioning over GPUs, metric gather).
 """
 from ._lib import InrHipError, InrHipUnavailable  # noqa: F401
 from .ops import InrDeviceError  # noqa: F401
-from .inr import (ImageFitting_set, PN, SineLayer, Siren, SirenFitter, calculate_ADC,  # noqa: F401
+from .inr import (ImageFitting_set, PN, ShardedSirenFitter, SineLayer, Siren, SirenFitter, calculate_ADC,  # noqa: F401
                   calculate_combinations, fit_siren, flat_parameters, get_mgrid, input_mapping, reconstruct,
                   resize_array)
 
-__all__ = ["ImageFitting_set", "PN", "SineLayer", "Siren", "SirenFitter", "calculate_ADC",
+__all__ = ["ImageFitting_set", "PN", "ShardedSirenFitter", "SineLayer", "Siren", "SirenFitter", "calculate_ADC",
            "calculate_combinations", "fit_siren", "flat_parameters", "get_mgrid", "input_mapping",
            "reconstruct", "resize_array", "InrHipError", "InrHipUnavailable", "InrDeviceError"]

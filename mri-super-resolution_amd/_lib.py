@@ -91,6 +91,8 @@ SIGNATURES = {
     "inr_rams_workspace_bytes": (C.c_size_t, [C.POINTER(RamsDesc), C.c_int, C.c_int, C.c_int]),
     "inr_rams_forward": (C.c_int, [C.POINTER(RamsDesc), c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_size_t, c_stream]),
+    "inr_siren_loss_grad": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64,
+                                      c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "inr_prof_enable": (C.c_int, [C.c_int]),
     "inr_prof_reset": (C.c_int, []),
     "inr_prof_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),

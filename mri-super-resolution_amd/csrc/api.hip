@@ -76,7 +76,7 @@ int gemm_tanh_forward(float* act, float* dact, const float* x, const float* W, c
                       int out_f, float scale, hipStream_t stream);
 int mse_blocks(int64_t count);
 int launch_mse(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
-               float* partial, hipStream_t st);
+               float* partial, hipStream_t st, int64_t count_total = 0);
 int launch_head_dz(float* dz, const float* gy, const float* W, const float* dact, int64_t n, int hidden,
                    int out_f, hipStream_t st);
 int64_t colsum_ws_floats(int64_t n, int C, int G);
@@ -500,6 +500,45 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     return c;
 }
 
+// one forward (with stash) + loss + backward of the layer-wise path; grads land in the flat gradient buffer.
+// count_total > 0: this is one row shard of a split fit (mean taken over count_total elements).
+static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
+                                std::vector<float*>& act, std::vector<float*>& dact, float* y, float* gy, float* scratch,
+                                const float* target, const float* weight, int64_t n, int64_t count_total,
+                                float* loss_dst, hipStream_t st) {
+    const int H = d->hidden_features, O = d->out_features, head = L.n_sine;
+    // forward with stash (SRDWI.py:58-59 per layer; dact = omega*cos(.) replaces autograd's saved z)
+    for (int l = 0; l < L.n_sine; ++l) {
+        const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        if (int rc = gemm_sine_forward(act[l + 1], dact[l], act[l], params + L.w_off[l], params + L.b_off[l], n,
+                                       L.fan_in[l], L.fan_out[l], omega, st))
+            return rc;
+    }
+    if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
+                                     0.f, st))
+        return rc;
+    // loss + dL/dy (superresDWI.py:135)
+    if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st, count_total)) return rc;
+    // backward: head, then sine layers from last to first; dz overwrites dact in place
+    // (bias gradients ride along: the head pass yields gb of the last sine layer, every input-grad GEMM
+    //  yields gb of the layer below from its epilogue)
+    if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
+                               grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
+                               H, O, scratch, st))
+        return rc;
+    for (int l = L.n_sine - 1; l >= 0; --l) {
+        if (int rc = param_grad(grads + L.w_off[l], nullptr, dact[l], act[l], n, L.fan_in[l], L.fan_out[l],
+                                scratch, st))
+            return rc;
+        if (l > 0) {
+            if (int rc = input_grad(dact[l - 1], grads + L.b_off[l - 1], dact[l], params + L.w_off[l], dact[l - 1],
+                                    n, L.fan_in[l], L.fan_out[l], scratch, st))
+                return rc;
+        }
+    }
+    return 0;
+}
+
 size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
     if (check_desc(desc) || n < 1) return 0;
     const Layout L = make_layout(desc);
@@ -532,8 +571,6 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
     float* gy = (float*)((char*)y + c.out_b);
     float* scratch = (float*)((char*)gy + c.out_b);
     float* loss_sink = scratch;  // overwritten later in the step; only used when losses == nullptr
-    const int H = desc->hidden_features, O = desc->out_features, head = L.n_sine;
-
     if (small_path_ok(desc, n) && !g_force_generic) {
         // master.py regime (small network, few thousand rows): one fused forward+backward launch + one reduce/Adam
         // launch per step instead of ~45 layer-wise launches (csrc/siren_small.hip)
@@ -549,39 +586,41 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
     }
 
     for (int it = 0; it < n_steps; ++it) {
-        // forward with stash (SRDWI.py:58-59 per layer; dact = omega*cos(.) replaces autograd's saved z)
-        for (int l = 0; l < L.n_sine; ++l) {
-            const float omega = (l == 0) ? desc->first_omega : desc->hidden_omega;
-            if (int rc = gemm_sine_forward(act[l + 1], dact[l], act[l], params + L.w_off[l], params + L.b_off[l], n,
-                                           L.fan_in[l], L.fan_out[l], omega, st))
-                return rc;
-        }
-        if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
-                                         0.f, st))
+        if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
+                                          losses ? (losses + it) : loss_sink, st))
             return rc;
-        // loss + dL/dy (superresDWI.py:135)
-        float* loss_dst = losses ? (losses + it) : loss_sink;
-        if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st)) return rc;
-        // backward: head, then sine layers from last to first; dz overwrites dact in place
-        // (bias gradients ride along: the head pass yields gb of the last sine layer, every input-grad GEMM
-        //  yields gb of the layer below from its epilogue)
-        if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
-                                   grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
-                                   H, O, scratch, st))
-            return rc;
-        for (int l = L.n_sine - 1; l >= 0; --l) {
-            if (int rc = param_grad(grads + L.w_off[l], nullptr, dact[l], act[l], n, L.fan_in[l], L.fan_out[l],
-                                    scratch, st))
-                return rc;
-            if (l > 0) {
-                if (int rc = input_grad(dact[l - 1], grads + L.b_off[l - 1], dact[l], params + L.w_off[l], dact[l - 1],
-                                        n, L.fan_in[l], L.fan_out[l], scratch, st))
-                    return rc;
-            }
-        }
         if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
     }
     return 0;
+}
+
+// forward + loss + backward only (no optimizer): the building block of a fit whose rows are split over GPUs
+int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
+                        const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(params && grads && x && target && loss, INR_E_INVALID, "inr_siren_loss_grad: null pointer");
+    INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_loss_grad: bad row count %lld", (long long)n);
+    INR_REQUIRE(count_total == 0 || count_total >= n * desc->out_features, INR_E_INVALID,
+                "inr_siren_loss_grad: count_total must be 0 or >= n*out_features");
+    const Layout L = make_layout(desc);
+    const FitCarve c = fit_carve(desc, L, n);
+    INR_REQUIRE(workspace && workspace_bytes >= c.total, INR_E_WORKSPACE,
+                "inr_siren_loss_grad: workspace too small (%zu < %zu)", workspace_bytes, c.total);
+    INR_REQUIRE(aligned16(workspace) && aligned16(params) && aligned16(grads) && aligned16(x), INR_E_ALIGN,
+                "inr_siren_loss_grad: params/grads/x/workspace must be 16-byte aligned");
+    char* base = (char*)workspace;
+    std::vector<float*> act(L.n_sine + 1), dact(L.n_sine);
+    act[0] = const_cast<float*>(x);
+    for (int l = 0; l < L.n_sine; ++l) {
+        act[l + 1] = (float*)(base + (size_t)l * c.act_b);
+        dact[l] = (float*)(base + (size_t)(L.n_sine + l) * c.act_b);
+    }
+    float* y = (float*)(base + 2 * (size_t)L.n_sine * c.act_b);
+    float* gy = (float*)((char*)y + c.out_b);
+    float* scratch = (float*)((char*)gy + c.out_b);
+    return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
+                                (hipStream_t)stream);
 }
 
 // ---- metrics ---------------------------------------------------------------------------------------------

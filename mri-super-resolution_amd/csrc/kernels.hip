@@ -358,15 +358,16 @@ int launch_head_forward(float* y, const float* a, const float* W, const float* b
 
 int mse_blocks(int64_t count) { return (int)blocks_for(count, 256 * 4, 2048); }
 
+// count_total (0 = count): the divisor of the mean -- larger than `count` when this call sees one row shard of a
+// fit that is split over several GPUs (gradients and losses of the shards then simply add up)
 int launch_mse(float* gy, float* loss, const float* y, const float* t, const float* w, int64_t count,
-               float* partial, hipStream_t st) {
+               float* partial, hipStream_t st, int64_t count_total = 0) {
     const int nb = mse_blocks(count);
+    const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : count));
     ProfScope ps(KC_OTHER, st);
-    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, gy, partial, y, t, w, count,
-                       (float)(1.0 / (double)count));
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, st, gy, partial, y, t, w, count, inv);
     INR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, loss, partial, nb,
-                       (float)(1.0 / (double)count));
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, loss, partial, nb, inv);
     INR_LAUNCH_CHECK();
     return 0;
 }

@@ -349,6 +349,49 @@ class SirenFitter:
         self._workspace = None
 
 
+class ShardedSirenFitter(SirenFitter):
+    """One fit whose coordinate rows are split over the ranks of a process group (SURVEY.md 8 e): every rank holds
+    identical weights and its own row shard; per step the local forward/backward (``inr_siren_loss_grad``, mean taken
+    over the GLOBAL row count) is followed by ONE all-reduce(sum) of the flat gradient (+ the loss) -- 3.68 MB for
+    Siren(256,512,3,1) over RCCL/xGMI -- and an identical local Adam step.  Mathematically the full-batch step of
+    superresDWI.py:134-138; the summation order differs from the single-GPU run (tier T3/T4 parity, not bitwise)."""
+
+    def __init__(self, model: Siren, global_rows: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
+        super().__init__(model, lr=lr, betas=betas, eps=eps)
+        self.global_rows = int(global_rows)
+        self.group = group
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        else:   # gloo (CPU tests): stage through host memory
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+
+    def step(self, model_input, target, n_steps=1, weight=None):
+        self._check_views()
+        x = model_input.detach().reshape(-1, model_input.shape[-1]).contiguous()
+        t = target.detach().reshape(-1).contiguous()
+        w = None if weight is None else weight.detach().reshape(-1).contiguous()
+        losses = torch.empty(max(int(n_steps), 1), dtype=torch.float32, device=x.device)
+        count_total = self.global_rows * self.desc.out_features
+        for it in range(int(n_steps)):
+            self._workspace = ops.siren_loss_grad(self.desc, self.flat, self.grads, x, t, w, count_total, self._loss,
+                                                  self._workspace)
+            self._all_reduce(self.grads)
+            self._all_reduce(self._loss)
+            self.step_count += 1
+            ops.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
+                          self.eps)
+            losses[it] = self._loss[0]
+        return losses[:n_steps]
+
+
 def flat_parameters(model: Siren):
     """Flat fp32 parameter buffer in the C ABI's layout (a copy; for inference entry points)."""
     desc = model.desc()

@@ -378,6 +378,30 @@ def siren_fit(desc: SirenDesc, params, grads, m, v, x, target, weight, first_ste
     return workspace
 
 
+def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_total: int, loss, workspace=None):
+    """Forward + loss + backward of one row shard (no optimizer); see ``inr_siren_loss_grad``."""
+    total, _ = siren_param_layout(desc)
+    for name, t in (("params", params), ("grads", grads)):
+        _chk(t, name)
+        if t.numel() != total:
+            raise ValueError(f"{name} has {t.numel()} floats, layout needs {total}")
+    _chk(x, "x")
+    _chk(target, "target")
+    _chk(loss, "loss")
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != desc.in_features or target.numel() != n * desc.out_features:
+        raise ValueError("x / target shape mismatch")
+    if weight is not None:
+        _chk(weight, "weight")
+    need = siren_fit_workspace_bytes(desc, n)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = _ws(need, x.device)
+    check(lib().inr_siren_loss_grad(C.byref(desc), params.data_ptr(), grads.data_ptr(), x.data_ptr(), target.data_ptr(),
+                                    _ptr(weight), n, int(count_total), loss.data_ptr(), workspace.data_ptr(),
+                                    workspace.numel() * workspace.element_size(), _stream()), "inr_siren_loss_grad")
+    return workspace
+
+
 # ---- measurement hooks ------------------------------------------------------------------------------------
 def prof_enable(on: bool):
     check(lib().inr_prof_enable(1 if on else 0))
