@@ -228,7 +228,7 @@ def main():
                       "per_gpu_rows": n_lr, "parallelism": f"{world} independent fits (one volume per GPU)"},
            "roofline": roofline}
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:   # single-GPU run only: the N > 1 runs measure scaling of the fit itself
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rec = inr.reconstruct(net, (2 * SIDE, 2 * SIDE, SIDE), B)
@@ -241,7 +241,7 @@ def main():
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
         out["cfg2_real_volume"] = cfg2_leg()
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, B_np, vol)
         out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))
