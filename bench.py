@@ -137,10 +137,15 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
+    device_index = local_rank % torch.cuda.device_count()   # (a rehearsal may put several ranks on one card)
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("INR_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N > 1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import mri_super_resolution_amd as inr
     from mri_super_resolution_amd import dist as inr_dist
