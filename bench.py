@@ -80,6 +80,7 @@ def cfg1_quality(inr, steps=2500):
     dt = time.perf_counter() - t0
     return {"config": "pat07 slice 11, 64x64 LR -> 128x128, 2500 steps, seed 0", "psnr_db": O.psnr(hr, rec.cpu().numpy()),
             "reference_cpu_psnr_db_seeds0to3": [32.59, 32.29, 32.37, 32.21], "final_loss": float(losses[-1]),
+            "median_loss_last_100": float(losses[-100:].median()),   # full-batch Adam spikes now and then at this loss level
             "fit_plus_recon_seconds": dt, "train_voxels_per_s": lr.size * steps / dt}
 
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof/* (rocprofv3 kernel trace + PMC passes of bench.py) into the committed profiles/ files."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+prof = os.path.join(root, "gpurun_out", "prof")
+out_dir = os.path.join(root, "profiles")
+shutil.copy(sorted(glob.glob(prof + "/kt/*/*_kernel_stats.csv"))[-1], os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+with open(os.path.join(out_dir, f"{tag}_bench_under_rocprof.json"), "w") as fh:
+    fh.write("".join(l for l in open(prof + "/kt.log") if l.startswith("{")))
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        if "inr::" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
+
+
+hbm = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+               "--no-extras`; per-dispatch averages in bytes (counter unit = KiB).  FETCH_SIZE is doubled per "
+               "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced 16-B/lane reads); WRITE_SIZE is exact.",
+       "kernels": {}}
+for name, sub, mult in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.0)):
+    for k, d in per_kernel(sorted(glob.glob(f"{prof}/{sub}/*/*counter_collection.csv"))[-1]).items():
+        (avg, n), = d.values()
+        e = hbm["kernels"].setdefault(k, {})
+        e[name + "_raw_bytes"], e[name + "_bytes"], e["dispatches"] = avg * 1024, avg * 1024 * mult, n
+tot_b = sum((d.get("fetch_bytes", 0) + d.get("write_bytes", 0)) * d["dispatches"] for k, d in hbm["kernels"].items() if "gemm_f32" in k)
+tot_n = sum(d["dispatches"] for k, d in hbm["kernels"].items() if "gemm_f32" in k)
+hbm["gemm_f32_avg_hbm_bytes_per_launch"] = tot_b / tot_n
+json.dump(hbm, open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+sq = {"note": "rocprofv3 --pmc (SQ/GRBM pass) on the same command; per-dispatch averages.  SQ_WAVE/WAIT/ACTIVE count quad-cycles, "
+              "SQ_VALU_MFMA_BUSY_CYCLES = MFMA pipe cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
+      "kernels": {k: {c: v[0] for c, v in d.items()} for k, d in per_kernel(sorted(glob.glob(prof + "/pmc_sq/*/*counter_collection.csv"))[-1]).items()}}
+for k, d in sq["kernels"].items():
+    if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
+        d["mfma_pipe_utilisation"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d["GRBM_GUI_ACTIVE"] / 8)
+json.dump(sq, open(os.path.join(out_dir, f"{tag}_pmc_sq.json"), "w"), indent=1)
+print("gemm avg HBM bytes per launch: %.0f MB" % (hbm["gemm_f32_avg_hbm_bytes_per_launch"] / 1e6))
+for k, d in sq["kernels"].items():
+    if "gemm" in k:
+        print(k[:70], "MFMA util %.3f  bank conflicts %.3g" % (d.get("mfma_pipe_utilisation", 0), d.get("SQ_LDS_BANK_CONFLICT", 0)))
