@@ -231,6 +231,15 @@ size_t  inr_rams_workspace_bytes(const inr_rams_desc_t* desc, int batch, int hei
 int inr_rams_forward(const inr_rams_desc_t* desc, const float* params, const float* x, float* out, int batch,
                      int height, int width, int clip_round, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- a-15 (loss side): RAMS shift-tolerant losses (multi-image-super-resolution/utils/loss.py:26-75 l1_loss, :77-127
+ * psnr).  y_true, y_pred, mask: [n_images][size][size] fp32.  For every label shift (i, j) in [0, 2*border]^2 the
+ * prediction cropped by `border` is compared with the shifted label window under the shifted mask after removing the
+ * masked mean brightness difference; out[b] (double) = min over shifts of the masked mean |.| (mode 0, cL1) or
+ * max over shifts of 10*log10(65535^2 / masked mean square) (mode 1, cPSNR; the reference then averages over b). */
+size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border);
+int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int n_images, int size,
+                        int border, int mode, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
  * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */
 int  inr_prof_enable(int enable);

@@ -98,6 +98,8 @@ int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t p
 int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
                 int use_mask, float mask_thr, double* ws, hipStream_t st);
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
+int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
+                      int border, int mode, double* ws, hipStream_t st);
 long long rams_param_floats(const inr_rams_desc_t* d);
 size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W);
 int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
@@ -650,6 +652,23 @@ int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int he
                 "inr_ssim2d: workspace too small");
     return launch_ssim(out, x, y, n_images, height, width, win, data_range, use_mask, mask_thr, (double*)workspace,
                        (hipStream_t)stream);
+}
+
+size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border) {
+    const int ns = 2 * (border > 0 ? border : 0) + 1;
+    return (size_t)(n_images > 0 ? n_images : 1) * ns * ns * sizeof(double);
+}
+
+int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int n_images, int size,
+                        int border, int mode, void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(out && y_true && y_pred && mask, INR_E_INVALID, "inr_rams_shift_loss: null pointer");
+    INR_REQUIRE(n_images >= 1 && n_images <= 65535 && border >= 0 && border <= 16 && size > 2 * border &&
+                    (mode == 0 || mode == 1),
+                INR_E_INVALID, "inr_rams_shift_loss: bad arguments (size=%d border=%d mode=%d)", size, border, mode);
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_shift_loss_workspace_bytes(n_images, border), INR_E_WORKSPACE,
+                "inr_rams_shift_loss: workspace too small");
+    return launch_shift_loss(out, y_true, y_pred, mask, n_images, size, border, mode, (double*)workspace,
+                             (hipStream_t)stream);
 }
 
 int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream) {

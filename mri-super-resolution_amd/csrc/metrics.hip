@@ -124,6 +124,57 @@ __global__ void __launch_bounds__(256) adc_kernel(float* __restrict__ out, const
     out[i] = (float)adc;
 }
 
+// ---- RAMS shift-tolerant losses (multi-image-super-resolution/utils/loss.py:26-75 l1_loss, :77-127 psnr) -----------
+// For each of the (2*border+1)^2 label shifts: brightness bias b = mean_masked(label - pred) over the cropped window,
+// then the masked mean of |label - (pred + b)| (mode 0) or of its square (mode 1).  One block per (shift, image),
+// fp64 accumulation, two passes over the (size - 2*border)^2 window.  y_true/y_pred/mask: [B][size][size] fp32.
+__global__ void __launch_bounds__(256) shift_loss_kernel(double* __restrict__ per_shift, const float* __restrict__ y_true,
+                                                         const float* __restrict__ y_pred, const float* __restrict__ mask,
+                                                         int size, int border, int mode) {
+    __shared__ double red[4];
+    const int nshift = 2 * border + 1;
+    const int si = blockIdx.x / nshift, sj = blockIdx.x % nshift, b = blockIdx.y;
+    const int c = size - 2 * border;
+    const float* yt = y_true + (long long)b * size * size;
+    const float* yp = y_pred + (long long)b * size * size;
+    const float* mk = mask + (long long)b * size * size;
+    double sm = 0.0, sd = 0.0;
+    for (int i = threadIdx.x; i < c * c; i += 256) {
+        const int r = i / c, q = i - r * c;
+        const double m = mk[(long long)(si + r) * size + sj + q];
+        sm += m;
+        sd += m * ((double)yt[(long long)(si + r) * size + sj + q] - (double)yp[(long long)(border + r) * size + border + q]);
+    }
+    sm = block_sum_f64(sm, red);
+    sd = block_sum_f64(sd, red);
+    const double bias = sd / sm;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < c * c; i += 256) {
+        const int r = i / c, q = i - r * c;
+        const double m = mk[(long long)(si + r) * size + sj + q];
+        // labels*m - (pred*m + b)*m  (loss.py:43-60)
+        const double d = m * (double)yt[(long long)(si + r) * size + sj + q] -
+                         m * (m * (double)yp[(long long)(border + r) * size + border + q] + bias);
+        acc += mode == 0 ? fabs(d) : d * d;
+    }
+    acc = block_sum_f64(acc, red);
+    if (threadIdx.x == 0) per_shift[(long long)b * nshift * nshift + blockIdx.x] = acc / sm;
+}
+
+// out[b] = min over shifts of cL1 (mode 0) / max over shifts of 10*log10(65535^2 / cMSE) (mode 1)
+__global__ void shift_loss_finish_kernel(double* __restrict__ out, const double* __restrict__ per_shift, int nshift2,
+                                         int mode, int nimg) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nimg) return;
+    double best = 0.0;
+    for (int k = 0; k < nshift2; ++k) {
+        const double v = per_shift[(long long)b * nshift2 + k];
+        const double val = mode == 0 ? v : 10.0 * log10(65535.0 * 65535.0 / v);
+        if (k == 0 || (mode == 0 ? val < best : val > best)) best = val;
+    }
+    out[b] = best;
+}
+
 constexpr int METRIC_BLOCKS = 64;
 
 int metric_workspace_doubles(int nimg) { return nimg * METRIC_BLOCKS; }
@@ -149,6 +200,17 @@ int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, in
     INR_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, ws, METRIC_BLOCKS,
                        (double)(H - 2 * pad) * (double)(W - 2 * pad), nimg);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
+                      int border, int mode, double* ws, hipStream_t st) {
+    const int ns = 2 * border + 1;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(shift_loss_kernel, dim3(ns * ns, nimg), dim3(256), 0, st, ws, y_true, y_pred, mask, size, border, mode);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(shift_loss_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, ws, ns * ns, mode, nimg);
     INR_LAUNCH_CHECK();
     return 0;
 }

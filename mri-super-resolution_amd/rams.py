@@ -148,3 +148,35 @@ def predict_case(model: RAMS, stack, sample_size=25, rng=None):
     batch = np.concatenate([lor[:, :, :, inx] for inx in subsets], axis=0).astype(np.float32)
     sr = predict_tensor(model, batch)[..., 0]
     return sr.double().mean(dim=0), subsets
+
+
+def _shift_loss(y_true, y_pred, y_mask, size, mode):
+    dev = ops.require_gpu()
+
+    def prep(t):
+        t = torch.as_tensor(np.asarray(t, np.float32) if not torch.is_tensor(t) else t).to(dev, torch.float32)
+        if t.dim() == 4 and t.shape[-1] == 1:
+            t = t[..., 0]
+        if t.dim() != 3 or t.shape[1] != size or t.shape[2] != size:
+            raise ValueError(f"expected [B, {size}, {size}(, 1)], got {tuple(t.shape)}")
+        return t.contiguous()
+
+    yt, yp, mk = prep(y_true), prep(y_pred), prep(y_mask)
+    if not (yt.shape == yp.shape == mk.shape):
+        raise ValueError("y_true / y_pred / y_mask shape mismatch")
+    B = yt.shape[0]
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    ws = torch.empty(lib().inr_rams_shift_loss_workspace_bytes(B, 3), dtype=torch.uint8, device=dev)
+    check(lib().inr_rams_shift_loss(out.data_ptr(), yt.data_ptr(), yp.data_ptr(), mk.data_ptr(), B, int(size), 3, mode,
+                                    ws.data_ptr(), ws.numel(), ops._stream()), "inr_rams_shift_loss")
+    return out
+
+
+def l1_loss(y_true, y_pred, y_mask, HR_SIZE=384):
+    """utils/loss.py:26-75: per image, the minimum over the 7x7 label shifts of the brightness-corrected masked L1."""
+    return _shift_loss(y_true, y_pred, y_mask, HR_SIZE, 0)
+
+
+def psnr(y_true, y_pred, y_mask, size_image=384):
+    """utils/loss.py:77-127: mean over the batch of the maximum cPSNR over the 7x7 shifts (data range 65535)."""
+    return _shift_loss(y_true, y_pred, y_mask, size_image, 1).mean()

@@ -137,3 +137,22 @@ def predict_tensor(params, x, **kw):
     """prediction.py:76-83: cast -> model -> clip [0, 2**16] -> round half to even."""
     sr = rams_forward(params, np.asarray(x, np.float32), **kw)
     return np.round(np.clip(sr, 0.0, 2.0 ** 16)).astype(np.float32)
+
+
+def shift_losses(y_true, y_pred, y_mask, size, border=3):
+    """utils/loss.py:26-127 restated in float64: returns (min cL1 per image, max cPSNR per image)."""
+    yt, yp, mk = (np.asarray(a, np.float64) for a in (y_true, y_pred, y_mask))
+    c = size - 2 * border
+    pred = yp[:, border:size - border, border:size - border]
+    l1s, ps = [], []
+    for i in range(2 * border + 1):
+        for j in range(2 * border + 1):
+            lab = yt[:, i:i + c, j:j + c]
+            m = mk[:, i:i + c, j:j + c]
+            pm, lm = pred * m, lab * m
+            tot = m.sum(axis=(1, 2))
+            b = ((lm - pm).sum(axis=(1, 2)) / tot)[:, None, None]
+            corr = (pm + b) * m
+            l1s.append(np.abs(lm - corr).sum(axis=(1, 2)) / tot)
+            ps.append(10.0 * np.log10(65535.0 ** 2 / (((lm - corr) ** 2).sum(axis=(1, 2)) / tot)))
+    return np.min(np.stack(l1s), axis=0), np.max(np.stack(ps), axis=0)

@@ -61,3 +61,20 @@ def test_rejects_unsupported_configs():
         rams.RAMS(3, 64, 3, 9, 8, 2).pack()
     with pytest.raises(ValueError):
         rams.RAMS(seed=0)(np.zeros((1, 8, 8, 5), np.float32))
+
+
+def test_shift_tolerant_losses_match_oracle():
+    """cL1 / cPSNR of utils/loss.py (7x7 shifts, brightness bias, masks) against the float64 restatement."""
+    rng = np.random.default_rng(7)
+    B, size = 3, 60
+    y_true = (rng.random((B, size, size)) * 40000 + 2000).astype(np.float32)
+    y_pred = np.roll(y_true, (1, -2), axis=(1, 2)) * 0.97 + 150 + rng.standard_normal((B, size, size)).astype(np.float32) * 30
+    mask = (rng.random((B, size, size)) > 0.15).astype(np.float32)
+    want_l1, want_ps = R.shift_losses(y_true, y_pred, mask, size)
+    got_l1 = rams.l1_loss(y_true, y_pred.astype(np.float32), mask, HR_SIZE=size).cpu().numpy()
+    got_ps = rams.psnr(y_true[..., None], y_pred.astype(np.float32)[..., None], mask[..., None], size_image=size).item()
+    assert np.allclose(got_l1, want_l1, rtol=1e-9)
+    assert got_ps == pytest.approx(want_ps.mean(), rel=1e-10)
+    # the planted shift (+1, -2 relative to the centre (3,3)) is the best one: loss far below the unshifted one
+    unshifted = np.abs((y_true - y_pred)[:, 3:-3, 3:-3]).mean()
+    assert (got_l1 < 0.5 * unshifted).all()
