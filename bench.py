@@ -26,7 +26,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA dense peak (32x32x2 and 16x16x4 alike)
 IN_F, HIDDEN, LAYERS, OUT_F = 256, 512, 3, 1
 SIDE = 128
 
@@ -216,7 +216,7 @@ def main():
     # forward 0.5+2 (layer 0) + 3*(1+2); input-grad 3*(1+1+1); param-grad 1.5 (layer 0) + 3*2  = 28 matrices
     algo_bytes = 28.0 * n_lr * HIDDEN * 4 / 11.0
     achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-    roofline = {"bound": "mfma", "kernel": "gemm_f32_pipe_kernel (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+    roofline = {"bound": "mfma", "kernel": "gemm_f32_pipe16_kernel (v_mfma_f32_16x16x4_f32)", "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes,

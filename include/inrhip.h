@@ -240,6 +240,18 @@ size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border);
 int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int n_images, int size,
                         int border, int mode, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- (f)-1: three-compartment hybrid fit (PIA.py:240-283 `three_compartment_fit` / `hybrid_fit`, called at
+ * superresHybrid.py:140).  signals: [n_voxels][16] fp64, b-major over b = {0,150,1000,1500} x TE = {0,13,93,143}
+ * (the order of PIA.py:263-265).  Runs scipy's bounded trust-region-reflective least squares (what
+ * curve_fit(method='trf', maxfev=5000) executes: 2-point Jacobian, x_scale = 1, ftol = xtol = gtol = 1e-8, exact
+ * trust-region solver) with the reference's p0 and bounds (PIA.py:269-272), one voxel per lane, fp64.
+ * params: [n_voxels][8] = D_ep, D_st, D_lu, T2_ep, T2_st, T2_lu, V_ep, V_st (p0 where the fit exhausts maxfev,
+ * PIA.py:276-277); status: scipy termination code (0 = maxfev, 1 gtol, 2 ftol, 3 xtol, 4 both); nfev; cost =
+ * half the residual sum of squares at the returned point.  Non-finite input is the caller's to reject
+ * (curve_fit(check_finite=True) raises). */
+int inr_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n_voxels,
+                   void* stream);
+
 /* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
  * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */
 int  inr_prof_enable(int enable);

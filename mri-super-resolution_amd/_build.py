@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libinrhip.so")
-SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "siren_small.hip")
+SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "siren_small.hip", "hybrid_fit.hip")
 
 
 def _stale() -> bool:

@@ -98,6 +98,8 @@ int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t p
 int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
                 int use_mask, float mask_thr, double* ws, hipStream_t st);
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
+int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
+                      hipStream_t st);
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
                       int border, int mode, double* ws, hipStream_t st);
 long long rams_param_floats(const inr_rams_desc_t* d);
@@ -652,6 +654,15 @@ int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int he
                 "inr_ssim2d: workspace too small");
     return launch_ssim(out, x, y, n_images, height, width, win, data_range, use_mask, mask_thr, (double*)workspace,
                        (hipStream_t)stream);
+}
+
+int inr_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n_voxels,
+                   void* stream) {
+    if (n_voxels == 0) return 0;
+    INR_REQUIRE(params && status && nfev && cost && signals, INR_E_INVALID, "inr_hybrid_fit: null pointer");
+    INR_REQUIRE(n_voxels > 0 && n_voxels <= ((int64_t)1 << 36), INR_E_INVALID, "inr_hybrid_fit: bad voxel count %lld",
+                (long long)n_voxels);
+    return launch_hybrid_fit(params, status, nfev, cost, signals, n_voxels, (hipStream_t)stream);
 }
 
 size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border) {

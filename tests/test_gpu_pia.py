@@ -1,0 +1,63 @@
+"""-m gpu: the three-compartment hybrid fit kernel against the reference's `PIA.hybrid_fit` golden
+outputs and against the CPU oracle (oracle/pia_oracle.py).  Acceptance rule and thresholds: tests/pia_common.py."""
+import numpy as np
+import pytest
+
+from mri_super_resolution_amd import pia
+from oracle import pia_oracle as P
+from tests import pia_common as C
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hybrid_fit_matches_reference_golden(golden):
+    g = golden("pia_hybrid.npz")
+    out = pia.hybrid_fit_device(g["signals"])
+    x = out["params"].cpu().numpy()
+    stats = C.check_against(x, C.pack(g["D"], g["T2"], g["v"]), out["cost"].cpu().numpy(), g["cost"],
+                            out["nfev"].cpu().numpy(), g["nfev"])
+    print(stats)
+    D, T2, v = pia.hybrid_fit(g["signals"])
+    assert np.array_equal(C.pack(D, T2, v), x) and np.allclose(v.sum(axis=1), 1.0)
+    assert set(np.unique(out["status"].cpu().numpy())) <= {1, 2, 3, 4}
+
+
+def test_hybrid_fit_matches_oracle_on_fresh_signals():
+    sig = np.concatenate([P.synthetic_signals(24, nz, seed=7 + k) for k, nz in enumerate((0.0, 0.01, 0.05))])
+    want, cost, nfev = [], [], []
+    for y in sig:
+        p, info = P.trf_fit(y, return_info=True)
+        want.append(p); cost.append(info["cost"]); nfev.append(info["nfev"])
+    out = pia.hybrid_fit_device(sig)
+    C.check_against(out["params"].cpu().numpy(), np.array(want), out["cost"].cpu().numpy(), np.array(cost),
+                    out["nfev"].cpu().numpy(), np.array(nfev))
+
+
+def test_hybrid_fit_properties_at_slice_size():
+    """A full 120x120 slice (superresHybrid.py:128-140): bounds respected, cost never above the starting cost, exact
+    recovery of noiseless signals' curves, ragged tail (n not a multiple of 64), determinism."""
+    n = 120 * 120 + 7
+    sig = P.synthetic_signals(n, 0.0, seed=3)
+    out = pia.hybrid_fit_device(sig)
+    x = out["params"].cpu().numpy()
+    assert np.all(x >= P.LB) and np.all(x <= P.UB)
+    cost0 = 0.5 * ((P.three_compartment(P.P0)[None] - sig) ** 2).sum(axis=1)
+    cost = out["cost"].cpu().numpy()
+    assert np.all(cost <= cost0 + 1e-9)
+    idx = np.arange(0, n, 97)
+    curves = np.stack([P.three_compartment(p) for p in x[idx]])
+    rel = np.linalg.norm(curves - sig[idx], axis=1) / np.linalg.norm(sig[idx], axis=1)
+    assert np.median(rel) < 1e-6 and rel.max() < 2e-3
+    again = pia.hybrid_fit_device(sig)
+    assert np.array_equal(again["params"].cpu().numpy(), x)
+
+
+def test_hybrid_fit_errors_and_empty():
+    with pytest.raises(ValueError):
+        pia.hybrid_fit(np.zeros((4, 15)))
+    bad = P.synthetic_signals(4, 0.0, seed=1)
+    bad[2, 5] = np.nan
+    with pytest.raises(ValueError):
+        pia.hybrid_fit(bad)
+    D, T2, v = pia.hybrid_fit(np.zeros((0, 16)))
+    assert D.shape == (0, 3)

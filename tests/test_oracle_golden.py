@@ -230,3 +230,59 @@ def test_psnr_ssim_analytic():
     x, y = np.full((20, 20), 0.3), np.full((20, 20), 0.5)
     c1 = 0.01 ** 2
     assert O.ssim2d(x, y) == pytest.approx((2 * .15 + c1) / (.09 + .25 + c1), rel=1e-9)
+
+
+# ---- (f)-1 three-compartment hybrid fit: restated scipy TRF pinned against the reference's hybrid_fit ----------------
+def test_hybrid_fit_oracle_vs_reference(golden):
+    from oracle import pia_oracle as PIA
+    from tests import pia_common as C
+    g = golden("pia_hybrid.npz")
+    sel = np.arange(0, 128, 2)      # 64 voxels, all four noise levels
+    x, cost, nfev = [], [], []
+    for y in g["signals"][sel]:
+        p, info = PIA.trf_fit(y, return_info=True)
+        x.append(p); cost.append(info["cost"]); nfev.append(info["nfev"])
+    ref = C.pack(g["D"], g["T2"], g["v"])[sel]
+    C.check_against(np.array(x), ref, np.array(cost), g["cost"][sel], np.array(nfev), g["nfev"][sel])
+    D, T2, v = PIA.hybrid_fit(g["signals"][:3])
+    assert np.allclose(v.sum(axis=1), 1.0) and D.shape == T2.shape == v.shape == (3, 3)
+
+
+def test_hybrid_fit_pieces_match_scipy():
+    """The restated building blocks against scipy's own (the reference's dependency), on random states incl. bounds."""
+    from scipy.optimize._lsq import common as SC, trf as ST
+    from scipy.optimize._numdiff import approx_derivative
+    from oracle import pia_oracle as PIA
+    rng = np.random.default_rng(0)
+    for trial in range(150):
+        y = PIA.synthetic_signals(1, 0.05, seed=trial)[0]
+        fun = lambda p: PIA.three_compartment(p) - y
+        x = rng.uniform(PIA.LB, PIA.UB)
+        k = rng.integers(0, 8, size=2)
+        if trial % 3 == 0:
+            x[k[0]] = np.nextafter(PIA.LB[k[0]], PIA.UB[k[0]])
+        if trial % 3 == 1:
+            x[k[1]] = np.nextafter(PIA.UB[k[1]], PIA.LB[k[1]])
+        f = fun(x)
+        J = PIA._fd_jacobian(fun, x, f)
+        assert np.array_equal(J, approx_derivative(fun, x, f0=f, bounds=(PIA.LB, PIA.UB), method="2-point"))
+        g = J.T @ f
+        v, dv = PIA._cl_scaling(x, g)
+        v2, dv2 = SC.CL_scaling_vector(x, g, PIA.LB, PIA.UB)
+        assert np.array_equal(v, v2) and np.array_equal(dv, dv2)
+        d, diag, gh, Jh = v ** 0.5, g * dv, v ** 0.5 * g, J * v ** 0.5
+        U, s, Vt = np.linalg.svd(np.vstack([Jh, np.diag(diag ** 0.5)]), full_matrices=False)
+        uf = U.T @ np.concatenate([f, np.zeros(8)])
+        delta = 10 ** rng.uniform(-3, 3)
+        a0 = 0.0 if trial % 2 else 10 ** rng.uniform(-3, 3)
+        p1, al1 = PIA._solve_tr(16, U[:16].T @ f, s, Vt.T, delta, a0)
+        p2, al2, _ = SC.solve_lsq_trust_region(8, 16, uf, s, Vt.T, delta, initial_alpha=a0)
+        assert np.allclose(p1, p2, rtol=1e-12, atol=0) and al1 == pytest.approx(al2, rel=1e-12)
+        theta = max(0.995, 1 - np.abs(g * v).max())
+        s1 = PIA._select_step(x, Jh, diag, gh, d * p1, p1.copy(), d, delta, theta)
+        s2 = ST.select_step(x, Jh, diag, gh, d * p2, p2.copy(), d, delta, PIA.LB, PIA.UB, theta)
+        for a, b in zip(s1, s2):
+            assert np.allclose(a, b, rtol=1e-10, atol=1e-300)
+        xb = x + s1[0]
+        xb[k[0]], xb[k[1]] = PIA.LB[k[0]], PIA.UB[k[1]]
+        assert np.array_equal(PIA._strictly_feasible(xb), SC.make_strictly_feasible(xb, PIA.LB, PIA.UB, rstep=0))
