@@ -119,6 +119,57 @@ def rams_leg(batch=25, reps=3):
             "flop_per_stack": 265.0e9}
 
 
+def cfg5_leg(steps=4):
+    """Config 5: one of the four TE fits of a synthetic 256^3 hybrid volume (superresHybrid.py:79-125): LR
+    128x128x256 = 4,194,304 rows per fit, Siren(256,512,3,1); a few fused steps (a full fit is 2,500)."""
+    from mri_super_resolution_amd import inr, ops
+    from oracle.torch_port import fourier_matrix
+    shape = (128, 128, 256)
+    n = shape[0] * shape[1] * shape[2]
+    x = ops.grid_fourier_map(shape, torch.from_numpy(fourier_matrix(3)).cuda())
+    target = torch.rand(n, device="cuda")
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1).cuda()
+    fitter = inr.SirenFitter(net, lr=1e-4)
+    fitter.step(x, target, n_steps=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fitter.step(x, target, n_steps=steps)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fitter.release_workspace()
+    return {"config": "synthetic 256^3, LR 128x128x256 (N=4194304 rows), Siren(256,512,3,1), fused steps",
+            "ms_per_step": dt * 1e3, "train_voxels_per_s": n / dt, "gemm_tflops_equiv": n * 5242880 / dt / 1e12}
+
+
+def hybrid_fit_leg(n=120 * 120 * 4):
+    """(f)-1: three-compartment fit of four 120x120 slices worth of voxels (PIA.hybrid_fit, superresHybrid.py:140),
+    2 % noise; next to scipy's curve_fit on 32 of the same voxels on one host core."""
+    from mri_super_resolution_amd import pia
+    from oracle import pia_oracle as P
+    from scipy.optimize import curve_fit
+    sig_np = P.synthetic_signals(n, 0.02, seed=5)
+    sig = torch.from_numpy(sig_np).cuda()
+    pia.hybrid_fit_device(sig[:6400])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pia.hybrid_fit_device(sig)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    f = lambda M, *p: P.three_compartment(np.array(p), M[0], M[1])
+    t0 = time.perf_counter()
+    for y in sig_np[:32]:
+        try:
+            curve_fit(f, np.vstack([P.B16, P.TE16]), y, p0=list(P.P0), bounds=(list(P.LB), list(P.UB)), method="trf",
+                      maxfev=5000)
+        except RuntimeError:
+            pass
+    dt_cpu = (time.perf_counter() - t0) / 32
+    return {"config": f"{n} voxels x 16 signals, 2% noise, fp64 TRF, maxfev 5000", "seconds": dt,
+            "voxel_fits_per_s": n / dt, "mean_nfev": float(out["nfev"].double().mean()),
+            "scipy_voxel_fits_per_s_1core": 1.0 / dt_cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +298,8 @@ def main():
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
         out["cfg2_real_volume"] = cfg2_leg()
+        out["cfg5_one_te_fit"] = cfg5_leg()
+        out["hybrid_fit"] = hybrid_fit_leg()
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, B_np, vol)
         out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]

@@ -419,6 +419,47 @@ def test_full_size_synthetic128_properties():
     assert O.rel_l2(host(gb), host(ref_gb)) < 1e-5
 
 
+def test_full_size_cfg5_256cube_properties():
+    """BASELINE config 5 (synthetic 256^3, superresHybrid-style LR [::2, ::2, :] -> N = 4,194,304 rows per fit,
+    ~75 GB of activations): 64-bit addressing of every kernel at 8x the bench size.  Properties: forward chunk
+    invariance on the LAST rows, oracle agreement on sampled rows, shard additivity of the fused loss/gradient,
+    and a decreasing loss over fused Adam steps."""
+    shape = (128, 128, 256)
+    n = shape[0] * shape[1] * shape[2]
+    B = dev(P.fourier_matrix(3))
+    x = ops.grid_fourier_map(shape, B)
+    assert x.shape == (n, 256)
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1).cuda()
+    desc, flat = inr.flat_parameters(net)
+    y_full = ops.siren_forward(desc, flat, x)
+    lo = n - 4099
+    assert torch.equal(y_full[lo:], ops.siren_forward(desc, flat, x[lo:].contiguous()))
+    rows = np.concatenate([np.random.default_rng(0).choice(n, 192, replace=False), np.arange(n - 64, n)])
+    ws = [host(p) for p in net.layer_parameters()[0::2]]
+    bs = [host(p) for p in net.layer_parameters()[1::2]]
+    want = O.siren_forward(ws, bs, host(x[torch.from_numpy(rows).cuda()]).astype(np.float64), dtype=np.float64)
+    assert O.rel_l2(host(y_full)[rows], want) < T1
+    del y_full
+    target = torch.rand(n, device="cuda")
+    g_full, g_a, g_b = (torch.zeros_like(flat) for _ in range(3))
+    l_full, l_a, l_b = (torch.zeros(1, device="cuda") for _ in range(3))
+    ops.siren_loss_grad(desc, flat, g_full, x, target, None, n, l_full)
+    h = n // 2 + 12345
+    ops.siren_loss_grad(desc, flat, g_a, x[:h].contiguous(), target[:h].contiguous(), None, n, l_a)
+    ops.siren_loss_grad(desc, flat, g_b, x[h:].contiguous(), target[h:].contiguous(), None, n, l_b)
+    torch.cuda.empty_cache()
+    assert O.rel_l2(host(g_a + g_b), host(g_full)) < 1e-5
+    assert (l_a + l_b).item() == pytest.approx(l_full.item(), rel=1e-5)
+    assert l_full.item() == pytest.approx(((ops.siren_forward(desc, flat, x).reshape(-1).double()
+                                            - target.double()) ** 2).mean().item(), rel=1e-5)
+    fitter = inr.SirenFitter(net, lr=1e-4)
+    losses = host(fitter.step(x, target, n_steps=3))
+    assert np.all(np.isfinite(losses)) and losses[0] == pytest.approx(l_full.item(), rel=1e-5)
+    assert losses[2] < losses[0]
+    fitter.release_workspace()
+
+
 # ------------------------------------------------------------------ a-10 PerturbNet --------------------------------
 def test_pn_forward_matches_reference(golden):
     p = golden("pn.npz")
