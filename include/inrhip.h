@@ -259,7 +259,9 @@ int  inr_prof_reset(void);
 /* synchronises the recorded events; returns launches and total milliseconds for a class */
 int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
 
-/* tuning/debug switches (not for production use): key 0 = force the generic GEMM kernel (0/1) */
+/* tuning/debug switches (not for production use): key 0 = force the generic GEMM kernel (0/1); key 1 = fp32 MFMA shape
+ * of the pipelined GEMM (1 = 16x16x4, default; 0 = 32x32x2); key 2 = hybrid-fit mapping (1 = eight lanes per voxel,
+ * default; 0 = one lane per voxel, kept as an independent cross-check) */
 int inr_debug_set(int key, int value);
 int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds) */
 

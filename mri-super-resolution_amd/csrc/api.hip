@@ -100,6 +100,7 @@ int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, in
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st);
+void set_hybrid_variant(int v);
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
                       int border, int mode, double* ws, hipStream_t st);
 long long rams_param_floats(const inr_rams_desc_t* d);
@@ -768,6 +769,7 @@ int inr_debug_set_ptr(int key, void* ptr) {
 int inr_debug_set(int key, int value) {
     if (key == 0) { g_force_generic = value; return 0; }
     if (key == 1) { g_mfma16 = value; return 0; }
+    if (key == 2) { set_hybrid_variant(value); return 0; }
     return INR_E_INVALID;
 }
 

@@ -1,13 +1,15 @@
 // the three-compartment "hybrid" fit (PIA.py:240-283, called at superresHybrid.py:140).
 // The reference loops over voxels in Python and calls scipy.optimize.curve_fit(method='trf') on each: 16 signals
-// S(b, TE), 8 bounded parameters, forward-difference Jacobian.  Here one lane owns one voxel and runs the same
+// S(b, TE), 8 bounded parameters, forward-difference Jacobian.  Here a group of eight lanes (default kernel, second half
+// of this file) or a single lane (first half: the simple twin, kept as a cross-check) owns one voxel and runs the same
 // trust-region-reflective iteration (scipy least_squares: trf_bounds, tr_solver='exact', x_scale=1,
 // ftol=xtol=gtol=1e-8, max_nfev=5000) entirely in fp64: bound-aware 2-point Jacobian, Coleman-Li scaling, one SVD of
 // the augmented scaled Jacobian per outer iteration (one-sided Jacobi on the 24x8 matrix instead of LAPACK gesdd),
 // More' iteration on the secular equation, reflected / Cauchy candidate steps, the same radius update and
 // termination tests.  oracle/pia_oracle.py is the line-by-line CPU twin.
-// Per-lane working set (J 16x8, augmented copy 24x8, V 8x8) lives in private (scratch) memory; the problem is
-// latency- not bandwidth-bound (a whole 120x120 slice is 225 waves).
+// Measured (MI355X, 120x120 slice, 2 % noise): one lane per voxel 4.5 s (per-lane working set in scratch, the slowest
+// voxel of the slice -- 5000 evaluations -- sets the time), eight lanes per voxel 0.28 s; 230,400 voxels 0.85 s
+// (271 k fits/s; scipy on one host core: 104 fits/s).
 #include "common.h"
 
 namespace inr {
@@ -430,11 +432,430 @@ __global__ void __launch_bounds__(64) hybrid_fit_kernel(double* __restrict__ par
     cost_out[vox] = cost;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Eight lanes per voxel.  The fit is a chain of a few dozen (worst case 5000) dependent iterations, so the time of a
+// slice is the time of its slowest voxels: latency per iteration is what matters, not lanes in flight.  Lane j of a
+// group owns parameter j / Jacobian column j / singular triplet j: the eight forward-difference columns are evaluated
+// at once, 8-vectors live one component per lane (reductions = 3 xor-shuffles), and the one-sided Jacobi SVD runs as
+// a round-robin tournament -- 7 rounds per sweep, 4 disjoint column pairs rotated at once, partners exchanged
+// through LDS.  Every group-uniform scalar (cost, radius, alpha, termination) is computed redundantly on the 8 lanes
+// from bitwise identical reductions, so control flow never diverges inside a group; different groups of a wave do
+// diverge (the wave serialises their paths), which only costs throughput of an otherwise idle machine.
+namespace g8 {
+
+constexpr int OFF_A = 0, OFF_V = 192, OFF_J = 256, OFF_EX = 384, OFF_EXN = 408, OFF_F = 432, OFF_FN = 448, OFF_Y = 464;
+constexpr int GSTRIDE = 481;   // doubles per group (odd multiple of a bank pair: groups land in different banks)
+
+__device__ __forceinline__ double gsum(double v) {
+    v += __shfl_xor(v, 1, 8);
+    v += __shfl_xor(v, 2, 8);
+    v += __shfl_xor(v, 4, 8);
+    return v;
+}
+__device__ __forceinline__ double gmax(double v) {
+    v = fmax(v, __shfl_xor(v, 1, 8));
+    v = fmax(v, __shfl_xor(v, 2, 8));
+    v = fmax(v, __shfl_xor(v, 4, 8));
+    return v;
+}
+__device__ __forceinline__ double gmin(double v) {
+    v = fmin(v, __shfl_xor(v, 1, 8));
+    v = fmin(v, __shfl_xor(v, 2, 8));
+    v = fmin(v, __shfl_xor(v, 4, 8));
+    return v;
+}
+__device__ __forceinline__ bool gany(bool b) {
+    int v = b ? 1 : 0;
+    v |= __shfl_xor(v, 1, 8);
+    v |= __shfl_xor(v, 2, 8);
+    v |= __shfl_xor(v, 4, 8);
+    return v != 0;
+}
+__device__ __forceinline__ double gget(double v, int k) { return __shfl(v, k, 8); }
+// LDS traffic between lanes of ONE wave: in-order in hardware, this only pins the compiler
+__device__ __forceinline__ void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the 24 exponentials of the model at parameters xj (3 per lane) -> ex[0..11] = exp(-b_k/1000 D_c), ex[12..23] = exp(-TE_k/T2_c)
+__device__ __forceinline__ void model_exps(double xj, int j, double* ex) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int e = 3 * j + q, k = e & 3;
+        const int c = (e >= 12 ? e - 12 : e) >> 2;
+        const double pc = gget(xj, e >= 12 ? 3 + c : c);
+        ex[e] = e >= 12 ? exp(-c_te[k] / pc) : exp(-c_b[k] / 1000.0 * pc);
+    }
+}
+
+// residual rows 2j and 2j+1 from published exponentials (operation order of PIA.py:246-251, no fused multiply-add)
+__device__ __forceinline__ void residual_pair(const double* ex, double xj, const double* y, int j, double* f0, double* f1) {
+#pragma clang fp contract(off)
+    const double v0 = gget(xj, 6), v1 = gget(xj, 7), v2 = 1.0 - v0 - v1;
+    const int ib = j >> 1, it = (j & 1) * 2;
+    const double e0 = ex[ib], e1 = ex[4 + ib], e2 = ex[8 + ib];
+    const double sa = (v0 * e0 * ex[12 + it] + v1 * e1 * ex[16 + it]) + v2 * e2 * ex[20 + it];
+    const double sb = (v0 * e0 * ex[13 + it] + v1 * e1 * ex[17 + it]) + v2 * e2 * ex[21 + it];
+    *f0 = 1000.0 * sa - y[2 * j];
+    *f1 = 1000.0 * sb - y[2 * j + 1];
+}
+
+// forward-difference Jacobian column j (scipy approx_derivative '2-point' with bounds), all 16 rows, in registers
+__device__ __forceinline__ void jac_column(double xj, int j, double lb, double ub, const double* ex, const double* f,
+                                           const double* y, double* Jc) {
+#pragma clang fp contract(off)
+    const double rstep = 1.4901161193847656e-08;
+    double h = rstep * (xj >= 0.0 ? 1.0 : -1.0) * fmax(1.0, fabs(xj));
+    const double lower = xj - lb, upper = ub - xj, xh = xj + h;
+    const bool violated = xh < lb || xh > ub, fitting = fabs(h) <= fmax(lower, upper);
+    if (violated && fitting) h = -h;
+    if (!fitting) h = upper >= lower ? upper : -lower;
+    const double x1 = xj + h, dx = x1 - xj;
+    double ne[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ne[k] = j < 3 ? exp(-c_b[k] / 1000.0 * x1) : exp(-c_te[k] / (j < 6 ? x1 : 1.0));
+    double eb[3][4], et[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            eb[c][k] = j == c ? ne[k] : ex[c * 4 + k];
+            et[c][k] = j == 3 + c ? ne[k] : ex[12 + c * 4 + k];
+        }
+    const double p6 = gget(xj, 6), p7 = gget(xj, 7);
+    const double v0 = j == 6 ? x1 : p6, v1 = j == 7 ? x1 : p7, v2 = 1.0 - v0 - v1;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const double s = (v0 * eb[0][ib] * et[0][it] + v1 * eb[1][ib] * et[1][it]) + v2 * eb[2][ib] * et[2][it];
+            const int r = ib * 4 + it;
+            Jc[r] = ((1000.0 * s - y[r]) - f[r]) / dx;
+        }
+}
+
+// rows 2j, 2j+1 of (J diag(d)) s, J published column-major in LDS
+__device__ __forceinline__ void jh_pair(const double* Jl, double ds, int j, double* o0, double* o1) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double w = gget(ds, i);
+        a0 += Jl[i * 16 + 2 * j] * w;
+        a1 += Jl[i * 16 + 2 * j + 1] * w;
+    }
+    *o0 = a0;
+    *o1 = a1;
+}
+
+__device__ __forceinline__ double eval_quad(const double* Jl, double d, double gh, double diag, double s, int j) {
+    double q0, q1;
+    jh_pair(Jl, d * s, j, &q0, &q1);
+    return 0.5 * gsum(q0 * q0 + q1 * q1 + s * diag * s) + gsum(s * gh);
+}
+
+__device__ __forceinline__ double bound_step(double x, double s, double lb, double ub, int* hit) {
+    const double st = s != 0.0 ? fmax((lb - x) / s, (ub - x) / s) : INFINITY;
+    const double t = gmin(st);
+    if (hit) *hit = st == t ? (s > 0.0 ? 1 : (s < 0.0 ? -1 : 0)) : 0;
+    return t;
+}
+
+}  // namespace g8
+
+__global__ void __launch_bounds__(64) hybrid_fit_g8_kernel(double* __restrict__ params, int* __restrict__ status_out,
+                                                           int* __restrict__ nfev_out, double* __restrict__ cost_out,
+                                                           const double* __restrict__ signals, int64_t n) {
+    using namespace g8;
+    __shared__ double lds[8 * GSTRIDE];
+    const int j = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int64_t vox = (int64_t)blockIdx.x * 8 + grp;
+    if (vox >= n) return;   // whole groups leave; nothing below synchronises across groups
+    double* L = lds + grp * GSTRIDE;
+    const double lb = c_lb[j], ub = c_ub[j];
+    L[OFF_Y + 2 * j] = signals[vox * HM + 2 * j];
+    L[OFF_Y + 2 * j + 1] = signals[vox * HM + 2 * j + 1];
+    double x = c_p0[j];
+    model_exps(x, j, L + OFF_EX);
+    lds_sync();
+    double f0, f1;
+    residual_pair(L + OFF_EX, x, L + OFF_Y, j, &f0, &f1);
+    L[OFF_F + 2 * j] = f0;
+    L[OFF_F + 2 * j + 1] = f1;
+    lds_sync();
+    double cost = 0.5 * gsum(f0 * f0 + f1 * f1);
+    int nfev = 1;
+    double Jc[HM], g;
+    auto new_jacobian = [&]() {
+        jac_column(x, j, lb, ub, L + OFF_EX, L + OFF_F, L + OFF_Y, Jc);
+        g = 0.0;
+#pragma unroll
+        for (int r = 0; r < HM; ++r) {
+            L[OFF_J + j * 16 + r] = Jc[r];
+            g += Jc[r] * L[OFF_F + r];
+        }
+        lds_sync();
+    };
+    new_jacobian();
+    auto scaling = [&](double* v, double* dv) {
+        *v = 1.0;
+        *dv = 0.0;
+        if (g < 0.0) { *v = ub - x; *dv = -1.0; }
+        if (g > 0.0) { *v = x - lb; *dv = 1.0; }
+    };
+    double v, dv;
+    scaling(&v, &dv);
+    double delta = sqrt(gsum((x / sqrt(v)) * (x / sqrt(v))));
+    if (delta == 0.0) delta = 1.0;
+    double alpha = 0.0;
+    int status = -1;
+    while (true) {
+        scaling(&v, &dv);
+        const double g_norm = gmax(fabs(g * v));
+        if (g_norm < H_TOL) status = 1;
+        if (status >= 0 || nfev == H_MAX_NFEV) break;
+        const double d = sqrt(v), diag = g * dv, gh = d * g;
+        // ---- SVD of [J diag(d); diag(sqrt(diag))]: one-sided Jacobi, column j here, partners through LDS ------------
+        double a[HA], vv[HN];
+#pragma unroll
+        for (int r = 0; r < HM; ++r) a[r] = Jc[r] * d;
+#pragma unroll
+        for (int r = 0; r < HN; ++r) {
+            a[HM + r] = r == j ? sqrt(diag) : 0.0;
+            vv[r] = r == j ? 1.0 : 0.0;
+        }
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            bool rot = false;
+            for (int t = 0; t < 7; ++t) {
+                int partner = j == 7 ? t : (j == t ? 7 : 2 * t - j);
+                if (j != 7 && j != t) partner = partner < 0 ? partner + 7 : (partner >= 7 ? partner - 7 : partner);
+#pragma unroll
+                for (int r = 0; r < HA; ++r) L[OFF_A + j * HA + r] = a[r];
+#pragma unroll
+                for (int r = 0; r < HN; ++r) L[OFF_V + j * HN + r] = vv[r];
+                lds_sync();
+                double b[HA], vb[HN], own2 = 0.0, oth2 = 0.0, ga = 0.0;
+#pragma unroll
+                for (int r = 0; r < HA; ++r) {
+                    b[r] = L[OFF_A + partner * HA + r];
+                    own2 += a[r] * a[r];
+                    oth2 += b[r] * b[r];
+                    ga += a[r] * b[r];
+                }
+#pragma unroll
+                for (int r = 0; r < HN; ++r) vb[r] = L[OFF_V + partner * HN + r];
+                lds_sync();
+                const bool first = j < partner;
+                const double al = first ? own2 : oth2, be = first ? oth2 : own2;
+                if (ga != 0.0 && ga * ga > 1e-30 * (al * be)) {
+                    rot = true;
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                    const double sg = first ? -s : s;   // column p: c a_p - s a_q ; column q: s a_p + c a_q
+#pragma unroll
+                    for (int r = 0; r < HA; ++r) a[r] = c * a[r] + sg * b[r];
+#pragma unroll
+                    for (int r = 0; r < HN; ++r) vv[r] = c * vv[r] + sg * vb[r];
+                }
+            }
+            if (!gany(rot)) break;
+        }
+        double s2 = 0.0, uy = 0.0;
+#pragma unroll
+        for (int r = 0; r < HA; ++r) s2 += a[r] * a[r];
+#pragma unroll
+        for (int r = 0; r < HM; ++r) uy += a[r] * L[OFF_F + r];
+#pragma unroll
+        for (int r = 0; r < HN; ++r) L[OFF_V + j * HN + r] = vv[r];
+        lds_sync();
+        const double sv = sqrt(s2), uf = sv > 0.0 ? uy / sv : 0.0, suf = sv * uf;
+        const double smax = gmax(sv), smin = gmin(sv);
+        const bool full_rank = smin > H_EPS * HM * smax;
+        auto v_times = [&](double w) {   // component j of -V w
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < HN; ++k) acc += L[OFF_V + k * HN + j] * gget(w, k);
+            return -acc;
+        };
+        const double theta = fmax(0.995, 1.0 - g_norm);
+        double actual = -1.0, cost_new = cost, x_new = x, fn0 = f0, fn1 = f1;
+        while (actual <= 0.0 && nfev < H_MAX_NFEV) {
+            // ---- trust-region sub-problem (More') -----------------------------------------------------------------
+            double ph;
+            bool gauss_newton = false;
+            if (full_rank) {
+                ph = v_times(uf / sv);
+                if (sqrt(gsum(ph * ph)) <= delta) {
+                    alpha = 0.0;
+                    gauss_newton = true;
+                }
+            }
+            if (!gauss_newton) {
+                double a_hi = sqrt(gsum(suf * suf)) / delta, a_lo = 0.0, fph, fpp;
+                auto phi = [&](double al) {
+                    const double den = sv * sv + al, q = suf / den;
+                    const double pn = sqrt(gsum(q * q));
+                    fph = pn - delta;
+                    fpp = -gsum(suf * suf / (den * den * den)) / pn;
+                };
+                if (full_rank) {
+                    phi(0.0);
+                    a_lo = -fph / fpp;
+                }
+                if (!full_rank && alpha == 0.0) alpha = fmax(0.001 * a_hi, sqrt(a_lo * a_hi));
+                for (int it = 0; it < 10; ++it) {
+                    if (alpha < a_lo || alpha > a_hi) alpha = fmax(0.001 * a_hi, sqrt(a_lo * a_hi));
+                    phi(alpha);
+                    if (fph < 0.0) a_hi = alpha;
+                    const double ratio = fph / fpp;
+                    a_lo = fmax(a_lo, alpha - ratio);
+                    alpha -= (fph + delta) * ratio / delta;
+                    if (fabs(fph) < 0.01 * delta) break;
+                }
+                ph = v_times(suf / (sv * sv + alpha));
+                ph *= delta / sqrt(gsum(ph * ph));
+            }
+            // ---- select_step: plain / reflected / Cauchy -----------------------------------------------------------
+            double step, step_h, predicted;
+            {
+                double p = d * ph;
+                const double xn = x + p;
+                if (!gany(xn < lb || xn > ub)) {
+                    step = p;
+                    step_h = ph;
+                    predicted = -eval_quad(L + OFF_J, d, gh, diag, ph, j);
+                } else {
+                    int hit;
+                    const double p_stride = bound_step(x, p, lb, ub, &hit);
+                    double rh = hit != 0 ? -ph : ph, r = d * rh;
+                    p *= p_stride;
+                    double phs = ph * p_stride;
+                    const double x_on = x + p;
+                    double to_tr;
+                    {
+                        const double qa = gsum(rh * rh), qb = gsum(phs * rh), qc = gsum(phs * phs) - delta * delta;
+                        const double dd = sqrt(qb * qb - qa * qc), q = -(qb + copysign(dd, qb));
+                        const double t1 = q / qa, t2 = qc / q;
+                        to_tr = t1 < t2 ? t2 : t1;
+                    }
+                    const double to_bound = bound_step(x_on, r, lb, ub, nullptr);
+                    const double r_stride = fmin(to_bound, to_tr);
+                    double r_lo, r_hi;
+                    if (r_stride > 0.0) {
+                        r_lo = (1.0 - theta) * p_stride / r_stride;
+                        r_hi = r_stride == to_bound ? theta * to_bound : to_tr;
+                    } else {
+                        r_lo = 0.0;
+                        r_hi = -1.0;
+                    }
+                    double r_val = INFINITY;
+                    if (r_lo <= r_hi) {
+                        double v0, v1, u0, u1;
+                        jh_pair(L + OFF_J, d * rh, j, &v0, &v1);
+                        jh_pair(L + OFF_J, d * phs, j, &u0, &u1);
+                        const double qa = 0.5 * (gsum(v0 * v0 + v1 * v1) + gsum(rh * diag * rh));
+                        const double qb = gsum(gh * rh) + gsum(u0 * v0 + u1 * v1) + gsum(phs * diag * rh);
+                        const double qc = 0.5 * gsum(u0 * u0 + u1 * u1) + gsum(gh * phs) + 0.5 * gsum(phs * diag * phs);
+                        double tq;
+                        min_quadratic_1d(qa, qb, r_lo, r_hi, qc, &tq, &r_val);
+                        rh = rh * tq + phs;
+                        r = rh * d;
+                    }
+                    p *= theta;
+                    phs *= theta;
+                    const double p_val = eval_quad(L + OFF_J, d, gh, diag, phs, j);
+                    double agh = -gh, ag = d * agh;
+                    const double tr2 = delta / sqrt(gsum(agh * agh));
+                    const double tb2 = bound_step(x, ag, lb, ub, nullptr);
+                    const double stride = tb2 < tr2 ? theta * tb2 : tr2;
+                    double ag_val, t_ag;
+                    {
+                        double v0, v1;
+                        jh_pair(L + OFF_J, d * agh, j, &v0, &v1);
+                        const double qa = 0.5 * (gsum(v0 * v0 + v1 * v1) + gsum(agh * diag * agh));
+                        const double qb = gsum(gh * agh);
+                        min_quadratic_1d(qa, qb, 0.0, stride, 0.0, &t_ag, &ag_val);
+                    }
+                    if (p_val < r_val && p_val < ag_val) {
+                        step = p; step_h = phs; predicted = -p_val;
+                    } else if (r_val < p_val && r_val < ag_val) {
+                        step = r; step_h = rh; predicted = -r_val;
+                    } else {
+                        step = ag * t_ag; step_h = agh * t_ag; predicted = -ag_val;
+                    }
+                }
+            }
+            // ---- trial point ----------------------------------------------------------------------------------------
+            {
+                double xn = x + step;
+                const double lo = xn - lb, up = ub - xn;
+                if (lo <= fmin(up, 0.0)) xn = nextafter(lb, ub);
+                else if (up <= fmin(lo, 0.0)) xn = nextafter(ub, lb);
+                x_new = xn;
+            }
+            model_exps(x_new, j, L + OFF_EXN);
+            lds_sync();
+            residual_pair(L + OFF_EXN, x_new, L + OFF_Y, j, &fn0, &fn1);
+            ++nfev;
+            const double sh_norm = sqrt(gsum(step_h * step_h));
+            if (gany(!isfinite(fn0) || !isfinite(fn1))) {
+                delta = 0.25 * sh_norm;
+                continue;
+            }
+            cost_new = 0.5 * gsum(fn0 * fn0 + fn1 * fn1);
+            actual = cost - cost_new;
+            double ratio;
+            if (predicted > 0.0) ratio = actual / predicted;
+            else if (predicted == 0.0 && actual == 0.0) ratio = 1.0;
+            else ratio = 0.0;
+            double delta_new = delta;
+            if (ratio < 0.25) delta_new = 0.25 * sh_norm;
+            else if (ratio > 0.75 && sh_norm > 0.95 * delta) delta_new = 2.0 * delta;
+            const double step_norm = sqrt(gsum(step * step));
+            const bool ft = actual < H_TOL * cost && ratio > 0.25;
+            const bool xt = step_norm < H_TOL * (H_TOL + sqrt(gsum(x * x)));
+            if (ft && xt) status = 4;
+            else if (ft) status = 2;
+            else if (xt) status = 3;
+            if (status >= 0) break;
+            alpha *= delta / delta_new;
+            delta = delta_new;
+        }
+        if (actual > 0.0) {
+            x = x_new;
+            f0 = fn0;
+            f1 = fn1;
+            cost = cost_new;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) L[OFF_EX + 3 * j + q] = L[OFF_EXN + 3 * j + q];
+            L[OFF_F + 2 * j] = f0;
+            L[OFF_F + 2 * j + 1] = f1;
+            lds_sync();
+            new_jacobian();
+        }
+    }
+    if (status < 0) status = 0;
+    params[vox * HN + j] = status == 0 ? c_p0[j] : x;   // PIA.py:276-277
+    if (j == 0) {
+        status_out[vox] = status;
+        nfev_out[vox] = nfev;
+        cost_out[vox] = cost;
+    }
+}
+
+static int g_hybrid_variant = 1;   // 1 = eight lanes per voxel (default), 0 = one lane per voxel (cross-check)
+void set_hybrid_variant(int v) { g_hybrid_variant = v; }
+
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st) {
     ProfScope ps(KC_OTHER, st);
-    hipLaunchKernelGGL(hybrid_fit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, params, status, nfev, cost,
-                       signals, n);
+    if (g_hybrid_variant == 1)
+        hipLaunchKernelGGL(hybrid_fit_g8_kernel, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, params, status, nfev,
+                           cost, signals, n);
+    else
+        hipLaunchKernelGGL(hybrid_fit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, params, status, nfev,
+                           cost, signals, n);
     INR_LAUNCH_CHECK();
     return 0;
 }

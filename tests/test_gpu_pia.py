@@ -61,3 +61,17 @@ def test_hybrid_fit_errors_and_empty():
         pia.hybrid_fit(bad)
     D, T2, v = pia.hybrid_fit(np.zeros((0, 16)))
     assert D.shape == (0, 3)
+
+
+def test_hybrid_fit_two_device_mappings_agree():
+    """Eight lanes per voxel (default) against the independent one-lane-per-voxel kernel."""
+    from mri_super_resolution_amd._lib import lib
+    sig = P.synthetic_signals(200, 0.02, seed=11)
+    a = pia.hybrid_fit_device(sig)
+    lib().inr_debug_set(2, 0)
+    try:
+        b = pia.hybrid_fit_device(sig)
+    finally:
+        lib().inr_debug_set(2, 1)
+    C.check_against(a["params"].cpu().numpy(), b["params"].cpu().numpy(), a["cost"].cpu().numpy(),
+                    b["cost"].cpu().numpy(), a["nfev"].cpu().numpy(), b["nfev"].cpu().numpy())
