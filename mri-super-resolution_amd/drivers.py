@@ -6,6 +6,8 @@
 * ``fit_slice_ensemble`` -- master.py:130-160: small raw-coordinate SIREN on K acquisitions of one 2-D slice, one
   weighted optimizer step per acquisition per epoch, snapshot-ensemble of the last ``seg`` epochs at x1 and
   x``scale``.
+* ``fit_hybrid`` -- superresHybrid.py:57-140: one 4-D (x, y, z, b) fit per echo time, re-scaling, normalisation by
+  the (b = 0, TE = 0) image and the three-compartment fit of one slice (``pia.hybrid_fit_device``).
 * ``run_volumes`` -- the patient loop (superresDWI.py:29) partitioned over one-process-per-GPU ranks with a final
   metric gather (``dist.py``).
 
@@ -45,7 +47,7 @@ def fourier_matrix(dim: int, mapping_size: int = 128, scale: float = 0.5, seed: 
 def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512, hidden_layers: int = 3,
                mapping_size: int = 128, ff_scale: float = 0.5, lr: float = 1e-4, seed: Optional[int] = 0,
                downsample: bool = True, upscale_axes: int = 2, evaluate: bool = True, chunk_steps: int = 250,
-               return_recon: bool = True) -> Dict[str, object]:
+               return_recon: bool = True, normalize: bool = True) -> Dict[str, object]:
     """One INR super-resolution fit of an N-D volume (first ``upscale_axes`` axes are in-plane).
 
     ``downsample=True``: the volume is the HR ground truth, training uses ``vol[::2, ::2, ...]`` and the result is
@@ -53,7 +55,7 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
     HR in-plane size.  ``downsample=False``: the volume itself is the training grid and is re-sampled at 2x.
     """
     vol = np.ascontiguousarray(volume, dtype=np.float32)
-    vmax = float(vol.max())
+    vmax = float(vol.max()) if normalize else 1.0       # superresHybrid normalises per (b, TE) before stacking (:57-63)
     vol = np.ascontiguousarray(vol / vmax)                                                     # superresDWI.py:50-55
     sl = tuple(slice(None, None, 2) if a < upscale_axes else slice(None) for a in range(vol.ndim))
     lr_vol = np.ascontiguousarray(vol[sl]) if downsample else vol
@@ -143,6 +145,48 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
 
 
 RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss")
+
+
+def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slice_index: Optional[int] = None,
+               steps: int = 2500, seed: Optional[int] = 0, **fit_kwargs) -> Dict[str, object]:
+    """superresHybrid.py:57-140.  ``hybrid_raw``: [X, Y, Z, 4 (b), 4 (TE)].  Per echo time one 4-D INR fit of the
+    ROI (LR = every second in-plane voxel, coordinates (x, y, z, b)), re-sampled at twice the ROI size; the 16
+    re-scaled images are normalised by the (b=0, TE=0) one (x1000) and one z-slice goes through the three-compartment
+    fit.  Returns the device tensor ``recon_hybrid`` [2sx, 2sy, Z, 4, 4] and numpy maps ``D``, ``T2``, ``v``
+    [2sx, 2sy, 3] plus timings."""
+    from . import pia
+    raw = np.asarray(hybrid_raw, dtype=np.float32)
+    if raw.ndim != 5 or raw.shape[3] != 4 or raw.shape[4] != 4:
+        raise ValueError(f"hybrid_raw must be [X, Y, Z, 4, 4], got {raw.shape}")
+    x0, x1, y0, y1 = roi if roi is not None else (0, raw.shape[0], 0, raw.shape[1])
+    maxes = raw.reshape(-1, 4, 4).max(axis=0)                                              # superresHybrid.py:57-63
+    norm = raw / maxes
+    sx, sy, nz = x1 - x0, y1 - y0, raw.shape[2]
+    recon_hybrid = torch.empty((2 * sx, 2 * sy, nz, 4, 4), dtype=torch.float32, device="cuda")
+    scale = torch.from_numpy(maxes).cuda()
+    t_fit = t_recon = 0.0
+    losses = []
+    for te in range(4):                                                                    # superresHybrid.py:79
+        vol = np.ascontiguousarray(norm[x0:x1, y0:y1, :, :, te])                           # (x, y, z, b)
+        res = fit_volume(vol, steps=steps, seed=None if seed is None else seed + te, evaluate=False, normalize=False,
+                         **fit_kwargs)
+        recon_hybrid[..., te] = res["recon"] * scale[:, te]                                # superresHybrid.py:121-122
+        t_fit += res["t_fit"]
+        t_recon += res["t_recon"]
+        losses.append(res["final_loss"])
+    k = nz // 2 if slice_index is None else int(slice_index)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sl = recon_hybrid[:, :, k].double()                                                    # [2sx, 2sy, 4, 4]
+    signals = (1000.0 * sl / (sl[..., 0:1, 0:1] + 1e-7)).reshape(-1, 16)                   # superresHybrid.py:131-138
+    fit = pia.hybrid_fit_device(signals)
+    x = fit["params"].cpu().numpy()
+    t_hybrid = time.perf_counter() - t0
+    shape = (2 * sx, 2 * sy, 3)
+    v = np.concatenate([x[:, 6:8], 1 - x[:, 6:7] - x[:, 7:8]], axis=1)
+    return {"recon_hybrid": recon_hybrid, "signals": signals, "D": x[:, 0:3].reshape(shape), "T2": x[:, 3:6].reshape(shape),
+            "v": v.reshape(shape), "status": fit["status"].cpu().numpy().reshape(shape[:2]), "t_fit": t_fit,
+            "t_recon": t_recon, "t_hybrid_fit": t_hybrid, "final_losses": losses, "slice_index": k}
 
 
 def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, **fit_kwargs) -> List[Dict[str, float]]:

@@ -95,3 +95,35 @@ def test_fit_volume_cfg2_short(golden):
     want = P.port_reconstruct(ref, (128, 128, 28), B)
     got = drivers.reconstruct(res["model"], (128, 128, 28), res["B"]).cpu().numpy()
     assert O.rel_l2(got, want) < 1e-4
+
+
+def test_fit_hybrid_flow_small():
+    """superresHybrid.py:57-140 on a small smooth phantom: four 4-D (x, y, z, b) fits, re-scaling, normalisation by
+    the (b0, TE0) image, three-compartment fit of one slice; the hybrid-fit stage is checked against the CPU oracle
+    on the very signals the driver produced."""
+    from oracle import pia_oracle as PO
+    from tests import pia_common as PC
+    X, Y, Z = 20, 16, 3
+    gx, gy = np.meshgrid(np.linspace(0, 1, X), np.linspace(0, 1, Y), indexing="ij")
+    par = np.stack([0.4 + 0.2 * gx, 0.9 + 0.5 * gy, 2.8 + 0 * gx, 30 + 30 * gx, 50 + 40 * gy, 700 + 0 * gx,
+                    0.2 + 0.3 * gx * gy, 0.3 + 0.2 * (1 - gx)], axis=-1)                      # [X, Y, 8]
+    sig = np.stack([[PO.three_compartment(par[i, j]) for j in range(Y)] for i in range(X)])     # [X, Y, 16], b-major
+    amp = 500.0 * (1.0 + 0.3 * np.sin(3 * gx) * np.cos(2 * gy))
+    raw = (amp[..., None] * sig / 1000.0).reshape(X, Y, 1, 4, 4) * np.linspace(1.0, 0.9, Z).reshape(1, 1, Z, 1, 1)
+    res = drivers.fit_hybrid(raw, roi=(2, 18, 2, 14), slice_index=1, steps=400, seed=0, hidden_features=128,
+                             hidden_layers=2, mapping_size=32)
+    assert tuple(res["recon_hybrid"].shape) == (32, 24, Z, 4, 4)
+    assert res["D"].shape == res["T2"].shape == res["v"].shape == (32, 24, 3)
+    assert np.allclose(res["v"].sum(axis=-1), 1.0)
+    x = np.concatenate([res["D"], res["T2"], res["v"][..., :2]], axis=-1).reshape(-1, 8)
+    assert np.all(x >= PO.LB) and np.all(x <= PO.UB)
+    signals = res["signals"].cpu().numpy()
+    assert signals.shape == (32 * 24, 16) and np.allclose(signals[:, 0], 1000.0, rtol=1e-5)
+    # sanity of the INR stage: every second re-sampled voxel is close to the smooth phantom on the ROI grid (the two
+    # endpoint-inclusive grids only coincide at the corners, and 400 steps of a small net are far from converged)
+    rec = res["recon_hybrid"][::2, ::2, 1].cpu().numpy()
+    want = raw[2:18, 2:14, 1]
+    assert O.rel_l2(rec, want) < 0.1
+    idx = np.arange(0, signals.shape[0], 13)
+    ref = np.array([PO.trf_fit(s) for s in signals[idx]])
+    PC.check_against(x[idx], ref)
