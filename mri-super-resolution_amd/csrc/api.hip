@@ -60,13 +60,17 @@ void prof_end(int kc, hipStream_t s) {
 
 // ---- kernels implemented in gemm_f32.hip / kernels.hip ------------------------------------------------
 int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
-                      int in_f, int out_f, float omega, hipStream_t stream);
+                      int in_f, int out_f, float omega, hipStream_t stream, const H3Args* h3 = nullptr);
 int input_grad_colsum_rows(int64_t n);
 int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
-                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream);
+                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream, const H3Args* h3 = nullptr);
+size_t h3_planes_bytes(long long weights);
+int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream);
+int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, _Float16* planes,
+                    unsigned* amax, unsigned* zero_slots, int n_zero, hipStream_t stream);
 int param_grad_splits(int64_t n, int in_f, int out_f);
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
-                          int out_f, hipStream_t stream);
+                          int out_f, hipStream_t stream, const H3Args* h3 = nullptr);
 int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, hipStream_t st);
 int launch_fourier(float* out, const float* x, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows,
                    const float* B, int m, hipStream_t st);
@@ -87,7 +91,7 @@ int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, 
 bool head_fused_ok(int hidden, int out_f, const void* a, const void* b, const void* c, const void* d);
 int64_t head_fused_blocks(int64_t n);
 int launch_head_bwd_fused(float* dz, float* slab_b, float* slab_w, const float* gy, const float* W, const float* a,
-                          const float* dact, int64_t n, int hidden, hipStream_t st);
+                          const float* dact, int64_t n, int hidden, hipStream_t st, unsigned* amax_out = nullptr);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr, double b1,
                 double b2, double eps, hipStream_t st);
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
@@ -114,6 +118,9 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
                    int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
 extern int g_force_generic;
 extern int g_mfma16;
+extern int g_h3;
+extern int g_h3_ablate;
+extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
@@ -163,10 +170,10 @@ static size_t param_grad_ws_floats(int64_t n, int in_f, int out_f) {
 
 // gW = dz^T x (row-split slabs + fixed-order reduce); gb = colsum(dz) when requested
 static int param_grad(float* gW, float* gb, const float* dz, const float* x, int64_t n, int in_f, int out_f,
-                      float* ws, hipStream_t st) {
+                      float* ws, hipStream_t st, const H3Args* h3 = nullptr) {
     const int splits = param_grad_splits(n, in_f, out_f);
     const int64_t len = (int64_t)in_f * out_f;
-    if (int rc = gemm_param_grad_slabs(ws, splits, dz, x, n, in_f, out_f, st)) return rc;
+    if (int rc = gemm_param_grad_slabs(ws, splits, dz, x, n, in_f, out_f, st, h3)) return rc;
     if (int rc = launch_reduce_slabs(gW, ws, splits, len, ws + (int64_t)splits * len, st)) return rc;
     if (gb) {
         if (int rc = launch_colsum(gb, dz, nullptr, n, out_f, 1, ws, st)) return rc;
@@ -182,13 +189,81 @@ static size_t input_grad_ws_floats(int64_t n, int in_f) {
 // dz_prev = (dz W) * dact_prev; gb_prev (nullable) = colsum(dz_prev), fused into the GEMM epilogue when the
 // fast kernel runs, otherwise a separate column-sum pass
 static int input_grad(float* dz_prev, float* gb_prev, const float* dz, const float* W, const float* dact_prev,
-                      int64_t n, int in_f, int out_f, float* ws, hipStream_t st) {
+                      int64_t n, int in_f, int out_f, float* ws, hipStream_t st, const H3Args* h3 = nullptr) {
     int slab_rows = 0;
     float* slab = (gb_prev && dact_prev) ? ws : nullptr;
-    if (int rc = gemm_input_grad(dz_prev, dz, W, dact_prev, n, in_f, out_f, slab, &slab_rows, st)) return rc;
+    if (int rc = gemm_input_grad(dz_prev, dz, W, dact_prev, n, in_f, out_f, slab, &slab_rows, st, h3)) return rc;
     if (!gb_prev) return 0;
     if (slab_rows > 0) return launch_reduce_slabs(gb_prev, ws, slab_rows, in_f, ws + (int64_t)slab_rows * in_f, st);
     return launch_colsum(gb_prev, dz_prev, nullptr, n, in_f, 1, ws, st);
+}
+
+// ---- split-fp16 GEMM context of a network (gemm_h3.inc): weight planes + scale slots inside the caller's workspace ----
+// slots: [l] = max|W_l|, [8 + l] = max|dz_l| (both rebuilt every step), [24] = max|x|
+struct H3Ctx {
+    bool on = false;
+    _Float16* planes = nullptr;
+    unsigned* slots = nullptr;
+    std::vector<long long> plane_off;   // halves, per sine layer
+};
+static bool h3_eligible(const Layout& L) {
+    if (!g_h3 || L.n_sine > 8) return false;
+    for (int l = 0; l < L.n_sine; ++l)
+        if (L.fan_in[l] % 32 != 0 || L.fan_out[l] % 32 != 0) return false;
+    return true;
+}
+static size_t h3_ctx_bytes(const Layout& L) {
+    long long w = 0;
+    for (int l = 0; l < L.n_sine; ++l) w += (long long)L.fan_in[l] * L.fan_out[l];
+    return round_up(256 + h3_planes_bytes(w), 256);
+}
+static H3Ctx h3_make_ctx(const Layout& L, char* region) {
+    H3Ctx c;
+    c.on = true;
+    c.slots = reinterpret_cast<unsigned*>(region);
+    c.planes = reinterpret_cast<_Float16*>(region + 256);
+    long long off = 0;
+    for (int l = 0; l < L.n_sine; ++l) {
+        c.plane_off.push_back(off);
+        off += 4ll * L.fan_in[l] * L.fan_out[l];
+    }
+    return c;
+}
+// split every sine layer's weights (once per optimizer step / forward call) and zero the dz slots
+static int h3_refresh_weights(const H3Ctx& c, const Layout& L, const float* params, hipStream_t st) {
+    const float* W[8];
+    int of[8], inf[8];
+    for (int l = 0; l < L.n_sine; ++l) {
+        W[l] = params + L.w_off[l];
+        of[l] = L.fan_out[l];
+        inf[l] = L.fan_in[l];
+    }
+    return h3_weight_split(W, of, inf, L.n_sine, c.planes, c.slots, c.slots, 16, st);
+}
+static H3Args h3_forward_args(const H3Ctx& c, const Layout& L, int l) {
+    H3Args a;
+    const long long n = (long long)L.fan_in[l] * L.fan_out[l];
+    a.a_amax = (l == 0) ? c.slots + 24 : nullptr;   // sine outputs are in [-1, 1]; the network input is whatever it is
+    a.b_amax = c.slots + l;
+    a.Bh = c.planes + c.plane_off[l];
+    a.Bl = a.Bh + n;
+    return a;
+}
+static H3Args h3_input_grad_args(const H3Ctx& c, const Layout& L, int l) {
+    H3Args a;
+    const long long n = (long long)L.fan_in[l] * L.fan_out[l];
+    a.a_amax = c.slots + 8 + l;
+    a.b_amax = c.slots + l;
+    a.Bh = c.planes + c.plane_off[l] + 2 * n;
+    a.Bl = a.Bh + n;
+    a.amax_out = c.slots + 8 + l - 1;
+    return a;
+}
+static H3Args h3_param_grad_args(const H3Ctx& c, int l) {
+    H3Args a;
+    a.a_amax = c.slots + 8 + l;
+    a.b_amax = (l == 0) ? c.slots + 24 : nullptr;
+    return a;
 }
 
 static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
@@ -203,13 +278,14 @@ static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
 // the bias gradient of the last sine layer.  One fused pass when out_features == 1.
 static int head_backward(float* dz_last, float* gW, float* gb, float* gb_last, const float* gy, const float* a_last,
                          const float* dact_last, const float* W, int64_t n, int hidden, int out_f, float* ws,
-                         hipStream_t st) {
+                         hipStream_t st, unsigned* dz_amax = nullptr) {
     if (dz_last && gW && dact_last && head_fused_ok(hidden, out_f, dz_last, a_last, dact_last, W)) {
         const int64_t blocks = head_fused_blocks(n);
         float* slab_b = ws;
         float* slab_w = ws + blocks * hidden;
         float* tmp = ws + 2 * blocks * hidden;
-        if (int rc = launch_head_bwd_fused(dz_last, slab_b, slab_w, gy, W, a_last, dact_last, n, hidden, st)) return rc;
+        if (int rc = launch_head_bwd_fused(dz_last, slab_b, slab_w, gy, W, a_last, dact_last, n, hidden, st, dz_amax))
+            return rc;
         if (gb_last) {
             if (int rc = launch_reduce_slabs(gb_last, slab_b, (int)blocks, hidden, tmp, st)) return rc;
         }
@@ -225,6 +301,9 @@ static int head_backward(float* dz_last, float* gW, float* gb, float* gb_last, c
     }
     if (dz_last) {
         if (int rc = launch_head_dz(dz_last, gy, W, dact_last, n, hidden, out_f, st)) return rc;
+        if (dz_amax) {
+            if (int rc = h3_tensor_amax(dz_amax, dz_last, (long long)n * hidden, st)) return rc;
+        }
         if (gb_last) return launch_colsum(gb_last, dz_last, nullptr, n, hidden, 1, ws, st);
     }
     return 0;
@@ -397,19 +476,25 @@ int inr_siren_param_offsets(const inr_siren_desc_t* desc, int64_t* offsets) {
 
 size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
     if (check_desc(desc)) return 0;
-    return 2 * round_up((size_t)(n > 0 ? n : 1) * desc->hidden_features * sizeof(float), 256);
+    return 2 * round_up((size_t)(n > 0 ? n : 1) * desc->hidden_features * sizeof(float), 256) +
+           h3_ctx_bytes(make_layout(desc));
 }
 
 static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const float* params, const float* x,
                               int64_t n, float* y, int use_clamp, float clamp_min, float* buf0, float* buf1,
-                              hipStream_t st) {
+                              hipStream_t st, const H3Ctx* h3 = nullptr) {
     const float* cur = x;
     float* bufs[2] = {buf0, buf1};
+    if (h3 && h3->on) {
+        if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st)) return rc;
+    }
     for (int l = 0; l < L.n_sine; ++l) {
         float* dst = bufs[l & 1];
         const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        H3Args ha;
+        if (h3 && h3->on) ha = h3_forward_args(*h3, L, l);
         if (int rc = gemm_sine_forward(dst, nullptr, cur, params + L.w_off[l], params + L.b_off[l], n, L.fan_in[l],
-                                       L.fan_out[l], omega, st))
+                                       L.fan_out[l], omega, st, (h3 && h3->on) ? &ha : nullptr))
             return rc;
         cur = dst;
     }
@@ -430,14 +515,19 @@ int inr_siren_forward(const inr_siren_desc_t* desc, const float* params, const f
     const size_t half = round_up((size_t)n * desc->hidden_features * sizeof(float), 256);
     float* b0 = (float*)workspace;
     float* b1 = (float*)((char*)workspace + half);
-    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream);
+    H3Ctx h3;
+    if (h3_eligible(L)) {
+        h3 = h3_make_ctx(L, (char*)workspace + 2 * half);
+        if (int rc = h3_refresh_weights(h3, L, params, (hipStream_t)stream)) return rc;
+    }
+    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream, &h3);
 }
 
 size_t inr_siren_reconstruct_workspace_bytes(const inr_siren_desc_t* desc, int64_t chunk_rows) {
     if (check_desc(desc) || chunk_rows < 1) return 0;
     const size_t feats = round_up((size_t)chunk_rows * desc->in_features * sizeof(float), 256);
     const size_t act = round_up((size_t)chunk_rows * desc->hidden_features * sizeof(float), 256);
-    return feats + 2 * act;
+    return feats + 2 * act + h3_ctx_bytes(make_layout(desc));
 }
 
 int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, const int64_t* shape, int dim,
@@ -469,13 +559,18 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
     float* b0 = (float*)((char*)workspace + feats_b);
     float* b1 = (float*)((char*)workspace + feats_b + act_b);
     hipStream_t st = (hipStream_t)stream;
+    H3Ctx h3;
+    if (h3_eligible(L)) {
+        h3 = h3_make_ctx(L, (char*)workspace + feats_b + 2 * act_b);
+        if (int rc = h3_refresh_weights(h3, L, params, st)) return rc;
+    }
     for (int64_t r0 = 0; r0 < total; r0 += chunk_rows) {
         const int64_t rows = (total - r0 < chunk_rows) ? (total - r0) : chunk_rows;
         int rc = B ? launch_fourier(feats, nullptr, shape, dim, r0, rows, B, m, st)
                    : launch_mgrid(feats, shape, dim, r0, rows, st);
         if (rc) return rc;
         rc = siren_forward_impl(desc, L, params, feats, rows, y + r0 * desc->out_features, use_clamp, clamp_min, b0,
-                                b1, st);
+                                b1, st, &h3);
         if (rc) return rc;
     }
     return 0;
@@ -483,7 +578,7 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
 
 // workspace carve for the fit: acts (n_sine x n x H), dacts (n_sine x n x H), y, gy, scratch
 struct FitCarve {
-    size_t act_b, out_b, scratch_b, total;
+    size_t act_b, out_b, scratch_b, total, h3_off;
 };
 static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n) {
     FitCarve c;
@@ -497,7 +592,8 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     const size_t mse = (size_t)mse_blocks((int64_t)n * d->out_features) + 1;
     if (mse > scratch) scratch = mse;
     c.scratch_b = round_up(scratch * sizeof(float), 256);
-    c.total = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
+    c.h3_off = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
+    c.total = c.h3_off + h3_ctx_bytes(L);
     if (small_path_ok(d, n)) {   // the fused small-network step carves the same workspace differently
         const size_t small = round_up(small_workspace_floats(d, n, L.total) * sizeof(float), 256);
         if (small > c.total) c.total = small;
@@ -510,13 +606,19 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
 static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
                                 std::vector<float*>& act, std::vector<float*>& dact, float* y, float* gy, float* scratch,
                                 const float* target, const float* weight, int64_t n, int64_t count_total,
-                                float* loss_dst, hipStream_t st) {
+                                float* loss_dst, hipStream_t st, const H3Ctx* h3 = nullptr) {
     const int H = d->hidden_features, O = d->out_features, head = L.n_sine;
+    const bool split = h3 && h3->on;
+    if (split) {   // this step's weights as fp16 planes; dz scale slots back to zero
+        if (int rc = h3_refresh_weights(*h3, L, params, st)) return rc;
+    }
     // forward with stash (SRDWI.py:58-59 per layer; dact = omega*cos(.) replaces autograd's saved z)
     for (int l = 0; l < L.n_sine; ++l) {
         const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        H3Args ha;
+        if (split) ha = h3_forward_args(*h3, L, l);
         if (int rc = gemm_sine_forward(act[l + 1], dact[l], act[l], params + L.w_off[l], params + L.b_off[l], n,
-                                       L.fan_in[l], L.fan_out[l], omega, st))
+                                       L.fan_in[l], L.fan_out[l], omega, st, split ? &ha : nullptr))
             return rc;
     }
     if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
@@ -529,15 +631,20 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
     //  yields gb of the layer below from its epilogue)
     if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
                                grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
-                               H, O, scratch, st))
+                               H, O, scratch, st, split ? h3->slots + 8 + head - 1 : nullptr))
         return rc;
     for (int l = L.n_sine - 1; l >= 0; --l) {
+        H3Args hp, hi;
+        if (split) {
+            hp = h3_param_grad_args(*h3, l);
+            if (l > 0) hi = h3_input_grad_args(*h3, L, l);
+        }
         if (int rc = param_grad(grads + L.w_off[l], nullptr, dact[l], act[l], n, L.fan_in[l], L.fan_out[l],
-                                scratch, st))
+                                scratch, st, split ? &hp : nullptr))
             return rc;
         if (l > 0) {
             if (int rc = input_grad(dact[l - 1], grads + L.b_off[l - 1], dact[l], params + L.w_off[l], dact[l - 1],
-                                    n, L.fan_in[l], L.fan_out[l], scratch, st))
+                                    n, L.fan_in[l], L.fan_out[l], scratch, st, split ? &hi : nullptr))
                 return rc;
         }
     }
@@ -590,9 +697,14 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
         return 0;
     }
 
+    H3Ctx h3;
+    if (h3_eligible(L)) {
+        h3 = h3_make_ctx(L, base + c.h3_off);
+        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], st)) return rc;
+    }
     for (int it = 0; it < n_steps; ++it) {
         if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
-                                          losses ? (losses + it) : loss_sink, st))
+                                          losses ? (losses + it) : loss_sink, st, &h3))
             return rc;
         if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
     }
@@ -624,8 +736,13 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
     float* y = (float*)(base + 2 * (size_t)L.n_sine * c.act_b);
     float* gy = (float*)((char*)y + c.out_b);
     float* scratch = (float*)((char*)gy + c.out_b);
+    H3Ctx h3;
+    if (h3_eligible(L)) {
+        h3 = h3_make_ctx(L, base + c.h3_off);
+        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream)) return rc;
+    }
     return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, &h3);
 }
 
 // ---- metrics ---------------------------------------------------------------------------------------------
@@ -763,12 +880,15 @@ int inr_prof_read(int kernel_class, int64_t* launches, double* total_ms) {
 
 int inr_debug_set_ptr(int key, void* ptr) {
     if (key == 0) { g_stamps = (unsigned long long*)ptr; return 0; }
+    if (key == 1) { g_h3_scratch = (char*)ptr; return 0; }
     return INR_E_INVALID;
 }
 
 int inr_debug_set(int key, int value) {
     if (key == 0) { g_force_generic = value; return 0; }
     if (key == 1) { g_mfma16 = value; return 0; }
+    if (key == 3) { g_h3 = value; return 0; }
+    if (key == 4) { g_h3_ablate = value; return 0; }
     if (key == 2) { set_hybrid_variant(value); return 0; }
     return INR_E_INVALID;
 }

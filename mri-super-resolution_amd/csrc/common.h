@@ -45,6 +45,15 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- per-kernel-class event profiler (bench.py roofline) ---------------------------------------
+// inputs of the split-fp16 GEMM path (gemm_h3.inc); a null pointer / default-constructed value selects the fp32 MFMA
+struct H3Args {
+    const unsigned* a_amax = nullptr;   // float bits of max|A| (dz operands); null: A unscaled (activations, |A| <= 1)
+    const unsigned* b_amax = nullptr;   // amax the pre-split B planes were scaled with
+    const _Float16* Bh = nullptr;       // pre-split weight planes, k-contiguous for the GEMM at hand
+    const _Float16* Bl = nullptr;
+    unsigned* amax_out = nullptr;       // input-grad: receives max|dz_prev|
+};
+
 enum KernelClass { KC_GEMM_FWD = 0, KC_GEMM_DX = 1, KC_GEMM_DW = 2, KC_OTHER = 3, KC_COUNT = 4 };
 bool prof_enabled();
 void prof_begin(int kernel_class, hipStream_t s);

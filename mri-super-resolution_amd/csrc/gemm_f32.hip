@@ -61,6 +61,14 @@ struct GemmParams {
     int tiles_m, tiles_n;
     long long a_elems, b_elems, c_elems;  // total element counts of A, B, C (SRD bounds of the fast path)
     unsigned long long* stamps;  // diagnostic builds (-DINR_STAMPS): 6 x u64 per wave
+    // split-fp16 path (gemm_h3.inc); all null/zero on the fp32 path
+    const unsigned* a_amax;      // float bits of max|A| (device); null = A is used unscaled (|A| <= 1: activations)
+    const unsigned* b_amax;      // same for B (for pre-split planes: the amax the planes were scaled with)
+    const _Float16* Bh;          // pre-split B planes (k-contiguous, leading dimension ldb halves)
+    const _Float16* Bl;
+    unsigned* amax_out;          // EPI_MUL: receives max|C| (atomic max on the float bits), nullable
+    int ablate;                  // diagnostics only (inr_debug_set(4, bits)): 1 no global loads in the K loop, 2 no split/park,
+                                 // 4 no fragment reads, 8 no epilogue -- results are garbage, timings tell what bounds the loop
 };
 
 template <bool KC>
@@ -403,6 +411,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __rest
     const float* rd = sub + (lane >> 4) * SUBS + (lane & 15) * 4;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     float zmax = 0.f;   // largest |omega*z| seen by this lane (sine epilogues)
+    float omax = 0.f;   // largest |output| (EPI_MUL with amax_out: scale of the next split-fp16 GEMM)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(rd + q * 4 * SUBS);
@@ -425,6 +434,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __rest
         } else if (EPI == EPI_MUL) {
             const f32x4 o = v * mulreg[q];   // rows past M: v == 0 and mulreg == 0, so they add nothing below
             csum += o;
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
             buf_store4(o, a.srdC, a.voff, so);
         } else {
             buf_store4(v, a.srdC, a.voff, so);
@@ -449,6 +459,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __rest
                 if (EPI == EPI_SINE_STASH) buf_store4(p.omega * cv, a.srdC2, a.voff, q * a.row_step);
             }
         }
+    }
+    if (EPI == EPI_MUL && p.amax_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(omax));   // max is order independent: runs stay reproducible
     }
     if (EPI == EPI_MUL && p.colsum) {
         // bias gradient of the layer below = column sums of this tile: 16 rows per lane, then the 4 lanes that
@@ -790,10 +805,15 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const Gemm
     epilogue_rows<EPI, SUB16>(p, sub, ea, mulreg, n0, wn, lane, tc.tile_m * 2 + wm);
 }
 
+#include "gemm_h3.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
 int g_mfma16 = 1;         // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
+int g_h3 = 1;             // split-fp16 GEMMs: 0 off, 1 on where the caller supplies scales/planes (fused fit), 2 also in
+                          // the standalone layer calls (debug: planes and amax built per call in g_h3_scratch)
+int g_h3_ablate = 0;
+char* g_h3_scratch = nullptr;   // inr_debug_set_ptr(1, ...): >= 16 MB of device memory for mode 2
 
 // ---- host-side launch --------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
@@ -812,6 +832,26 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
                       (a_span + (long long)BK * p.lda) * 4 < (1ll << 31) &&
                       (b_span + (long long)BK * p.ldb) * 4 < (1ll << 31);
     if (used_fast) *used_fast = fast;
+    if (fast && p.Bh && EPI != EPI_TANH && EPI != EPI_TANH_STASH) {
+        if constexpr (A_KC && B_KC) {
+            if (p.a_amax)
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, true, false, EPI>), grid, block, 0, stream, p);
+            else
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, false, false, EPI>), grid, block, 0, stream, p);
+            INR_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if constexpr (!A_KC && !B_KC && EPI == EPI_PLAIN) {
+        if (fast && p.a_amax) {
+            if (p.b_amax)
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, true, EPI>), grid, block, 0, stream, p);
+            else
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, false, EPI>), grid, block, 0, stream, p);
+            INR_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (fast && g_mfma16)
         hipLaunchKernelGGL((gemm_f32_pipe16_kernel<A_KC, B_KC, EPI>), grid, block, 0, stream, p);
     else if (fast)
@@ -829,9 +869,78 @@ static inline bool vec_ok(const void* a, const void* b, int lda, int ldb, int ka
 }
 
 // act[n][out] = sin(omega*(x[n][in] W[out][in]^T + b)), optional dact = omega*cos(...)
+// ---- split-fp16 support ---------------------------------------------------------------------------
+// layout of a weight-plane set for one [out][in] matrix inside a caller-provided region: hi, lo, hiT, loT (halves)
+size_t h3_planes_bytes(long long weights) { return (size_t)weights * 4 * sizeof(_Float16); }
+
+int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, _Float16* planes,
+                    unsigned* amax, unsigned* zero_slots, int n_zero, hipStream_t stream) {
+    INR_REQUIRE(layers >= 1 && layers <= 8, INR_E_INVALID, "h3_weight_split: %d layers", layers);
+    WeightSplitJobs jobs{};
+    _Float16* cur = planes;
+    for (int l = 0; l < layers; ++l) {
+        const long long n = (long long)out_f[l] * in_f[l];
+        jobs.job[l] = WeightSplitJob{W[l], cur, cur + n, cur + 2 * n, cur + 3 * n, amax + l, out_f[l], in_f[l]};
+        cur += 4 * n;
+    }
+    if (n_zero > 0) INR_HIP(hipMemsetAsync(zero_slots, 0, sizeof(unsigned) * n_zero, stream));
+    int max_tiles = 1;
+    for (int l = 0; l < layers; ++l) {
+        const int t = ((out_f[l] + 63) / 64) * ((in_f[l] + 63) / 64);
+        if (t > max_tiles) max_tiles = t;
+    }
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(weight_amax_kernel, dim3(32, layers), dim3(256), 0, stream, jobs);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(weight_split_kernel, dim3(max_tiles, layers), dim3(256), 0, stream, jobs);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream) {
+    INR_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), stream));
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(tensor_amax_kernel, dim3(1024), dim3(256), 0, stream, out, x, n);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline bool h3_shape_ok(int in_f, int out_f) { return in_f % BK == 0 && out_f % 8 == 0 && in_f % 8 == 0; }
+
+// debug mode 2: build planes / amax for a standalone layer call inside g_h3_scratch
+static int h3_debug_prepare(H3Args& h, const float* W, int out_f, int in_f, bool transposed, const float* scaled_a,
+                            long long a_elems, hipStream_t stream) {
+    unsigned* slots = reinterpret_cast<unsigned*>(g_h3_scratch);
+    if (W) {
+        _Float16* planes = reinterpret_cast<_Float16*>(g_h3_scratch + 256);
+        if (int rc = h3_weight_split(&W, &out_f, &in_f, 1, planes, slots, slots, 1, stream)) return rc;
+        const long long n = (long long)out_f * in_f;
+        h.Bh = planes + (transposed ? 2 * n : 0);
+        h.Bl = planes + (transposed ? 3 * n : n);
+        h.b_amax = slots;
+    }
+    if (scaled_a) {
+        if (int rc = h3_tensor_amax(slots + 1, scaled_a, a_elems, stream)) return rc;
+        h.a_amax = slots + 1;
+    }
+    return 0;
+}
+
+static inline void h3_apply(GemmParams& p, const H3Args* h) {
+    if (!h) return;
+    p.a_amax = h->a_amax; p.b_amax = h->b_amax; p.Bh = h->Bh; p.Bl = h->Bl; p.amax_out = h->amax_out;
+    p.ablate = g_h3_ablate;
+}
+
 int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
-                      int in_f, int out_f, float omega, hipStream_t stream) {
+                      int in_f, int out_f, float omega, hipStream_t stream, const H3Args* h3) {
+    H3Args dbg;
+    if (!h3 && g_h3 == 2 && g_h3_scratch && h3_shape_ok(in_f, out_f) && (long long)in_f * out_f <= (1 << 20)) {
+        if (int rc = h3_debug_prepare(dbg, W, out_f, in_f, false, nullptr, 0, stream)) return rc;
+        h3 = &dbg;
+    }
     GemmParams p{};
+    h3_apply(p, h3);
     p.A = x; p.B = W; p.C = act; p.C2 = dact; p.bias = b; p.mul = nullptr;
     p.M = (int)n; p.N = out_f; p.K = in_f;
     p.lda = in_f; p.ldb = in_f; p.ldc = out_f;
@@ -870,11 +979,18 @@ int gemm_tanh_forward(float* act, float* dact, const float* x, const float* W, c
 int input_grad_colsum_rows(int64_t n) { return 2 * (int)((n + BM - 1) / BM); }
 
 int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
-                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream) {
+                    int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream, const H3Args* h3) {
+    H3Args dbg;
+    if (!h3 && g_h3 == 2 && g_h3_scratch && h3_shape_ok(out_f, in_f) && (long long)in_f * out_f <= (1 << 20)) {
+        if (int rc = h3_debug_prepare(dbg, W, out_f, in_f, true, dz, (long long)n * out_f, stream)) return rc;
+        h3 = &dbg;
+    }
     GemmParams p{};
+    h3_apply(p, h3);
+    // with planes, B = W^T [in][out]: k-contiguous, leading dimension out_f
     p.A = dz; p.B = W; p.C = dz_prev; p.C2 = nullptr; p.bias = nullptr; p.mul = mul;
     p.M = (int)n; p.N = in_f; p.K = out_f;
-    p.lda = out_f; p.ldb = in_f; p.ldc = in_f;
+    p.lda = out_f; p.ldb = p.Bh ? out_f : in_f; p.ldc = in_f;
     p.omega = 0.f;
     p.splits = 1;
     p.k_per_split = (out_f + BK - 1) / BK * BK;
@@ -887,10 +1003,12 @@ int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float
     if (mul) {
         p.colsum = (in_f % 4 == 0) ? colsum_slab : nullptr;
         bool fast = false;
-        const int rc = launch_gemm<true, false, EPI_MUL>(p, vec, stream, &fast);
+        const int rc = p.Bh ? launch_gemm<true, true, EPI_MUL>(p, vec, stream, &fast)
+                            : launch_gemm<true, false, EPI_MUL>(p, vec, stream, &fast);
         if (rc == 0 && fast && p.colsum && slab_rows) *slab_rows = input_grad_colsum_rows(n);
         return rc;
     }
+    if (p.Bh) return launch_gemm<true, true, EPI_PLAIN>(p, vec, stream);
     return launch_gemm<true, false, EPI_PLAIN>(p, vec, stream);
 }
 
@@ -908,8 +1026,14 @@ int param_grad_splits(int64_t n, int in_f, int out_f) {
 
 // slabs[splits][out][in] = partial dz^T x over row ranges
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
-                          int out_f, hipStream_t stream) {
+                          int out_f, hipStream_t stream, const H3Args* h3) {
+    H3Args dbg;
+    if (!h3 && g_h3 == 2 && g_h3_scratch) {
+        if (int rc = h3_debug_prepare(dbg, nullptr, 0, 0, false, dz, (long long)n * out_f, stream)) return rc;
+        h3 = &dbg;
+    }
     GemmParams p{};
+    h3_apply(p, h3);
     p.A = dz; p.B = x; p.C = slabs; p.C2 = nullptr; p.bias = nullptr; p.mul = nullptr;
     p.M = out_f; p.N = in_f; p.K = (int)n;
     p.lda = out_f; p.ldb = in_f; p.ldc = in_f;

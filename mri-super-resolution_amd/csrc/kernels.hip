@@ -175,7 +175,8 @@ constexpr int HEAD_ROWS_PER_BLOCK = 256;
 __global__ void __launch_bounds__(256) head_bwd_fused_kernel(float* dz, float* __restrict__ slab_b,
                                                              float* __restrict__ slab_w, const float* __restrict__ gy,
                                                              const float* __restrict__ W, const float* __restrict__ a,
-                                                             const float* dact, int64_t n, int hidden) {
+                                                             const float* dact, int64_t n, int hidden,
+                                                             unsigned* __restrict__ amax_out) {
     __shared__ f32x4 red[2][256];
     const int Q = hidden >> 2;           // float4 groups per row (divides 256)
     const int RP = 256 / Q;              // rows per pass
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(256) head_bwd_fused_kernel(float* dz, float* _
     const int64_t r1 = min(n, r0 + HEAD_ROWS_PER_BLOCK);
     const f32x4 w4 = *reinterpret_cast<const f32x4*>(W + 4 * c4);
     f32x4 sb = {0.f, 0.f, 0.f, 0.f}, sw = {0.f, 0.f, 0.f, 0.f};
+    float omax = 0.f;   // max |dz| (scale of the split-fp16 GEMMs that consume dz); max is order independent
     for (int64_t r = r0 + rsub; r < r1; r += RP) {
         const float g = gy[r];
         const int64_t off = r * hidden + 4 * c4;
@@ -191,8 +193,14 @@ __global__ void __launch_bounds__(256) head_bwd_fused_kernel(float* dz, float* _
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(a + off);
         const f32x4 o = (g * w4) * d4;
         *reinterpret_cast<f32x4*>(dz + off) = o;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         sb += o;
         sw += g * a4;
+    }
+    if (amax_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+        if ((threadIdx.x & 63) == 0 && omax > 0.f) atomicMax(amax_out, __float_as_uint(omax));
     }
     red[0][threadIdx.x] = sb;
     red[1][threadIdx.x] = sw;
@@ -447,10 +455,10 @@ bool head_fused_ok(int hidden, int out_f, const void* a, const void* b, const vo
 }
 int64_t head_fused_blocks(int64_t n) { return (n + HEAD_ROWS_PER_BLOCK - 1) / HEAD_ROWS_PER_BLOCK; }
 int launch_head_bwd_fused(float* dz, float* slab_b, float* slab_w, const float* gy, const float* W, const float* a,
-                          const float* dact, int64_t n, int hidden, hipStream_t st) {
+                          const float* dact, int64_t n, int hidden, hipStream_t st, unsigned* amax_out) {
     ProfScope ps(KC_OTHER, st);
     hipLaunchKernelGGL(head_bwd_fused_kernel, dim3((unsigned)head_fused_blocks(n)), dim3(256), 0, st, dz, slab_b,
-                       slab_w, gy, W, a, dact, n, hidden);
+                       slab_w, gy, W, a, dact, n, hidden, amax_out);
     INR_LAUNCH_CHECK();
     return 0;
 }
