@@ -5,7 +5,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 prof = os.path.join(root, "gpurun_out", "prof")
 out_dir = os.path.join(root, "profiles")
-shutil.copy(sorted(glob.glob(prof + "/kt/*/*_kernel_stats.csv"))[-1], os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+def newest(pattern):
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+
+shutil.copy(newest(prof + "/kt/**/*_kernel_stats.csv"), os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
 with open(os.path.join(out_dir, f"{tag}_bench_under_rocprof.json"), "w") as fh:
     fh.write("".join(l for l in open(prof + "/kt.log") if l.startswith("{")))
 
@@ -23,17 +27,19 @@ hbm = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `be
                "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced 16-B/lane reads); WRITE_SIZE is exact.",
        "kernels": {}}
 for name, sub, mult in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.0)):
-    for k, d in per_kernel(sorted(glob.glob(f"{prof}/{sub}/*/*counter_collection.csv"))[-1]).items():
+    for k, d in per_kernel(newest(f"{prof}/{sub}/**/*counter_collection.csv")).items():
         (avg, n), = d.values()
         e = hbm["kernels"].setdefault(k, {})
         e[name + "_raw_bytes"], e[name + "_bytes"], e["dispatches"] = avg * 1024, avg * 1024 * mult, n
-tot_b = sum((d.get("fetch_bytes", 0) + d.get("write_bytes", 0)) * d["dispatches"] for k, d in hbm["kernels"].items() if "gemm_f32" in k)
-tot_n = sum(d["dispatches"] for k, d in hbm["kernels"].items() if "gemm_f32" in k)
-hbm["gemm_f32_avg_hbm_bytes_per_launch"] = tot_b / tot_n
+for fam in ("gemm_f32", "gemm_h3"):
+    tot_b = sum((d.get("fetch_bytes", 0) + d.get("write_bytes", 0)) * d["dispatches"] for k, d in hbm["kernels"].items() if fam in k)
+    tot_n = sum(d["dispatches"] for k, d in hbm["kernels"].items() if fam in k)
+    if tot_n:
+        hbm[fam + "_avg_hbm_bytes_per_launch"] = tot_b / tot_n
 json.dump(hbm, open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 sq = {"note": "rocprofv3 --pmc (SQ/GRBM pass) on the same command; per-dispatch averages.  SQ_WAVE/WAIT/ACTIVE count quad-cycles, "
               "SQ_VALU_MFMA_BUSY_CYCLES = MFMA pipe cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
-      "kernels": {k: {c: v[0] for c, v in d.items()} for k, d in per_kernel(sorted(glob.glob(prof + "/pmc_sq/*/*counter_collection.csv"))[-1]).items()}}
+      "kernels": {k: {c: v[0] for c, v in d.items()} for k, d in per_kernel(newest(prof + "/pmc_sq/**/*counter_collection.csv")).items()}}
 for k, d in sq["kernels"].items():
     if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
         d["mfma_pipe_utilisation"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d["GRBM_GUI_ACTIVE"] / 8)
