@@ -180,7 +180,12 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
  * forward with stash -> MSE (+optional weights) -> backward -> Adam, all enqueued on `stream`,
  * no host sync.  params/grads/m/v are flat buffers of inr_siren_param_count floats.  losses[n_steps]
  * (device, nullable) receives the loss of every step.  first_step is the 1-based Adam step of the
- * first iteration (so a fit can be continued). */
+ * first iteration (so a fit can be continued).
+ * Arithmetic: when every sine layer is a multiple of 32 wide, the three dense contractions of a step run on the fp16
+ * matrix cores with hi/lo-split operands (three fp16 products per fp32 product, fp32 accumulation, power-of-two
+ * tensor scales from exact on-device maxima) -- fp32-class accuracy, same parity tolerances; otherwise
+ * (and in every stand-alone layer entry point above) on the f32-input MFMA.  The workspace holds the fp16 weight
+ * planes of that path; size it with the query function. */
 size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n);
 int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, float* m, float* v,
                   const float* x, const float* target, const float* weight, int64_t n,
@@ -261,9 +266,14 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
 
 /* tuning/debug switches (not for production use): key 0 = force the generic GEMM kernel (0/1); key 1 = fp32 MFMA shape
  * of the pipelined GEMM (1 = 16x16x4, default; 0 = 32x32x2); key 2 = hybrid-fit mapping (1 = eight lanes per voxel,
- * default; 0 = one lane per voxel, kept as an independent cross-check) */
+ * default; 0 = one lane per voxel, kept as an independent cross-check); key 3 = GEMM arithmetic of the whole-network
+ * entry points (inr_siren_fit / _loss_grad / _forward / _reconstruct): 1 = split-fp16 MFMA (three fp16 products of
+ * hi/lo-split operands per fp32 product, fp32 accumulate; default), 0 = f32-input MFMA, 2 = split-fp16 also in the
+ * stand-alone layer calls (needs a >= 32 MiB device scratch buffer via inr_debug_set_ptr(1, ptr)); key 4 = ablation
+ * bits for tools/h3_ablate.py (results become garbage) */
 int inr_debug_set(int key, int value);
-int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds) */
+int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds);
+                                                 key 1: device scratch for debug key 3 = 2 */
 
 /* diagnostic: s[i] = sin(x[i]), c[i] = cos(x[i]) with the device routine used in the epilogues */
 int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream);

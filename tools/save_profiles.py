@@ -44,7 +44,9 @@ for k, d in sq["kernels"].items():
     if "GRBM_GUI_ACTIVE" in d and "SQ_VALU_MFMA_BUSY_CYCLES" in d and d["GRBM_GUI_ACTIVE"] > 0:
         d["mfma_pipe_utilisation"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * d["GRBM_GUI_ACTIVE"] / 8)
 json.dump(sq, open(os.path.join(out_dir, f"{tag}_pmc_sq.json"), "w"), indent=1)
-print("gemm avg HBM bytes per launch: %.0f MB" % (hbm["gemm_f32_avg_hbm_bytes_per_launch"] / 1e6))
+for key in ("gemm_f32_avg_hbm_bytes_per_launch", "gemm_h3_avg_hbm_bytes_per_launch"):
+    if key in hbm:
+        print("%s: %.0f MB" % (key, hbm[key] / 1e6))
 for k, d in sq["kernels"].items():
     if "gemm" in k:
         print(k[:70], "MFMA util %.3f  bank conflicts %.3g" % (d.get("mfma_pipe_utilisation", 0), d.get("SQ_LDS_BANK_CONFLICT", 0)))
