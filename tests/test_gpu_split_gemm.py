@@ -137,3 +137,34 @@ def test_fused_fit_split_vs_fp32_trajectory():
     assert np.allclose(out[0][0][:3], out[1][0][:3], rtol=1e-5)     # same arithmetic to fp32 noise at the start ...
     assert np.allclose(out[0][0], out[1][0], rtol=2e-3)             # ... which the steep first descent then amplifies
     assert np.linalg.norm(out[0][1] - out[1][1]) / np.linalg.norm(out[0][1]) < 1e-4
+
+
+@pytest.mark.parametrize("n,fin,hidden,layers,out", [(300, 64, 96, 2, 1), (1111, 32, 160, 1, 3), (64, 256, 512, 3, 1),
+                                                      (40000, 32, 32, 4, 1)])
+def test_fused_gradients_on_eligible_but_ragged_networks(n, fin, hidden, layers, out):
+    """Networks the split path accepts (every sine layer a multiple of 32 wide) whose sizes are not tile multiples:
+    fused forward/backward (lr = 0 step) against the per-layer autograd path on the f32 MFMA kernels, and both against
+    the float64 oracle forward."""
+    import mri_super_resolution_amd as inr
+    from oracle import inr_oracle as O
+    from oracle import torch_port as P
+    torch.manual_seed(n)
+    net = inr.Siren(fin, hidden, layers, out).cuda()
+    x = (torch.rand(n, fin, device="cuda") * 2 - 1).contiguous()
+    t = torch.rand(n, out, device="cuda")
+    y = net(x)
+    ((y - t) ** 2).mean().backward()
+    auto = torch.cat([p.grad.reshape(-1) for p in net.layer_parameters()]).double()
+    fitter = inr.SirenFitter(net, lr=0.0)
+    loss = fitter.step(x, t.reshape(-1), n_steps=1)
+    fused = torch.cat([fitter.grads[o:o + p.numel()] for (wo, bo), pw, pb in
+                       zip(fitter.offsets, net.layer_parameters()[0::2], net.layer_parameters()[1::2])
+                       for o, p in ((wo, pw), (bo, pb))]).double()
+    assert ((fused - auto).norm() / auto.norm()).item() < 5e-6
+    assert loss[0].item() == pytest.approx(((y - t) ** 2).mean().item(), rel=1e-5)
+    desc, flat = inr.flat_parameters(net)
+    ws = [p.detach().cpu().numpy() for p in net.layer_parameters()[0::2]]
+    bs = [p.detach().cpu().numpy() for p in net.layer_parameters()[1::2]]
+    want = O.siren_forward(ws, bs, x.cpu().numpy().astype(np.float64), dtype=np.float64)
+    got = ops.siren_forward(desc, flat, x).cpu().numpy()
+    assert O.rel_l2(got, want) < 1e-5
