@@ -120,6 +120,7 @@ extern int g_force_generic;
 extern int g_mfma16;
 extern int g_h3;
 extern int g_h3_ablate;
+static int g_h3_serpentine = 1;
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
 
@@ -247,6 +248,7 @@ static H3Args h3_forward_args(const H3Ctx& c, const Layout& L, int l) {
     a.b_amax = c.slots + l;
     a.Bh = c.planes + c.plane_off[l];
     a.Bl = a.Bh + n;
+    a.reverse_m = g_h3_serpentine ? (l & 1) : 0;      // layer l+1 starts where layer l stopped writing
     return a;
 }
 static H3Args h3_input_grad_args(const H3Ctx& c, const Layout& L, int l) {
@@ -257,12 +259,16 @@ static H3Args h3_input_grad_args(const H3Ctx& c, const Layout& L, int l) {
     a.Bh = c.planes + c.plane_off[l] + 2 * n;
     a.Bl = a.Bh + n;
     a.amax_out = c.slots + 8 + l - 1;
+    // backward chain: head pass (front to back) -> dW_L (back to front) -> dX_L (front to back) -> dW_{L-1} ... : every
+    // kernel starts on the rows the one before it touched last
+    a.reverse_m = 0;
     return a;
 }
 static H3Args h3_param_grad_args(const H3Ctx& c, int l) {
     H3Args a;
     a.a_amax = c.slots + 8 + l;
     a.b_amax = (l == 0) ? c.slots + 24 : nullptr;
+    a.reverse_m = g_h3_serpentine ? 1 : 0;
     return a;
 }
 
@@ -889,6 +895,7 @@ int inr_debug_set(int key, int value) {
     if (key == 1) { g_mfma16 = value; return 0; }
     if (key == 3) { g_h3 = value; return 0; }
     if (key == 4) { g_h3_ablate = value; return 0; }
+    if (key == 5) { g_h3_serpentine = value; return 0; }
     if (key == 2) { set_hybrid_variant(value); return 0; }
     return INR_E_INVALID;
 }

@@ -52,6 +52,7 @@ struct H3Args {
     const _Float16* Bh = nullptr;       // pre-split weight planes, k-contiguous for the GEMM at hand
     const _Float16* Bl = nullptr;
     unsigned* amax_out = nullptr;       // input-grad: receives max|dz_prev|
+    int reverse_m = 0;                  // serpentine row-tile order between consecutive kernels (Infinity Cache reuse)
 };
 
 enum KernelClass { KC_GEMM_FWD = 0, KC_GEMM_DX = 1, KC_GEMM_DW = 2, KC_OTHER = 3, KC_COUNT = 4 };

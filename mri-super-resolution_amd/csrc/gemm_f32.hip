@@ -67,6 +67,8 @@ struct GemmParams {
     const _Float16* Bh;          // pre-split B planes (k-contiguous, leading dimension ldb halves)
     const _Float16* Bl;
     unsigned* amax_out;          // EPI_MUL: receives max|C| (atomic max on the float bits), nullable
+    int reverse_m;               // walk the row tiles from the end: the rows the previous kernel wrote last (still in the
+                                 // 256 MB Infinity Cache) are read first
     int ablate;                  // diagnostics only (inr_debug_set(4, bits)): 1 no global loads in the K loop, 2 no split/park,
                                  // 4 no fragment reads, 8 no epilogue -- results are garbage, timings tell what bounds the loop
 };
@@ -96,6 +98,10 @@ __device__ __forceinline__ TileCoord decode_block(const GemmParams& p) {
     logical /= p.tiles_n;
     c.tile_m = logical % p.tiles_m;
     c.split = logical / p.tiles_m;
+    if (p.reverse_m) {   // row tiles (or, for the row-split parameter gradient, row ranges) from the end
+        if (p.splits > 1) c.split = p.splits - 1 - c.split;
+        else c.tile_m = p.tiles_m - 1 - c.tile_m;
+    }
     return c;
 }
 
@@ -929,6 +935,7 @@ static int h3_debug_prepare(H3Args& h, const float* W, int out_f, int in_f, bool
 static inline void h3_apply(GemmParams& p, const H3Args* h) {
     if (!h) return;
     p.a_amax = h->a_amax; p.b_amax = h->b_amax; p.Bh = h->Bh; p.Bl = h->Bl; p.amax_out = h->amax_out;
+    p.reverse_m = h->reverse_m;
     p.ablate = g_h3_ablate;
 }
 
