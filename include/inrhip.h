@@ -269,8 +269,9 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * default; 0 = one lane per voxel, kept as an independent cross-check); key 3 = GEMM arithmetic of the whole-network
  * entry points (inr_siren_fit / _loss_grad / _forward / _reconstruct): 1 = split-fp16 MFMA (three fp16 products of
  * hi/lo-split operands per fp32 product, fp32 accumulate; default), 0 = f32-input MFMA, 2 = split-fp16 also in the
- * stand-alone layer calls (needs a >= 32 MiB device scratch buffer via inr_debug_set_ptr(1, ptr)); key 4 = ablation
- * bits for tools/h3_ablate.py (results become garbage) */
+ * stand-alone layer calls (needs a >= 32 MiB device scratch buffer via inr_debug_set_ptr(1, ptr)); key 5 = serpentine
+ * row-tile order between consecutive GEMMs (1 default, 0 off); key 6 = 128 x 256 tiles for the forward GEMMs (1
+ * default, 0 = 128 x 128) */
 int inr_debug_set(int key, int value);
 int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds);
                                                  key 1: device scratch for debug key 3 = 2 */

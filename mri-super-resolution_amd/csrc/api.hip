@@ -119,7 +119,7 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
 extern int g_force_generic;
 extern int g_mfma16;
 extern int g_h3;
-extern int g_h3_ablate;
+extern int g_h3_wide;
 static int g_h3_serpentine = 1;
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
@@ -894,8 +894,8 @@ int inr_debug_set(int key, int value) {
     if (key == 0) { g_force_generic = value; return 0; }
     if (key == 1) { g_mfma16 = value; return 0; }
     if (key == 3) { g_h3 = value; return 0; }
-    if (key == 4) { g_h3_ablate = value; return 0; }
     if (key == 5) { g_h3_serpentine = value; return 0; }
+    if (key == 6) { g_h3_wide = value; return 0; }
     if (key == 2) { set_hybrid_variant(value); return 0; }
     return INR_E_INVALID;
 }

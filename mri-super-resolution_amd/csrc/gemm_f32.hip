@@ -30,6 +30,7 @@
 //   * tried without effect: start-time staggering of co-resident blocks or of the whole first wave, s_setprio in
 //     either direction; tried and slower: a persistent grid with cross-tile operand prefetch (-4 %).
 #include "common.h"
+#include <type_traits>
 
 namespace inr {
 
@@ -69,8 +70,6 @@ struct GemmParams {
     unsigned* amax_out;          // EPI_MUL: receives max|C| (atomic max on the float bits), nullable
     int reverse_m;               // walk the row tiles from the end: the rows the previous kernel wrote last (still in the
                                  // 256 MB Infinity Cache) are read first
-    int ablate;                  // diagnostics only (inr_debug_set(4, bits)): 1 no global loads in the K loop, 2 no split/park,
-                                 // 4 no fragment reads, 8 no epilogue -- results are garbage, timings tell what bounds the loop
 };
 
 template <bool KC>
@@ -818,7 +817,7 @@ int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM
 int g_mfma16 = 1;         // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
 int g_h3 = 1;             // split-fp16 GEMMs: 0 off, 1 on where the caller supplies scales/planes (fused fit), 2 also in
                           // the standalone layer calls (debug: planes and amax built per call in g_h3_scratch)
-int g_h3_ablate = 0;
+int g_h3_wide = 1;        // forward GEMMs on 128 x 256 tiles (inr_debug_set(6, 0): 128 x 128 everywhere)
 char* g_h3_scratch = nullptr;   // inr_debug_set_ptr(1, ...): >= 16 MB of device memory for mode 2
 
 // ---- host-side launch --------------------------------------------------------------------------
@@ -840,10 +839,19 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
     if (used_fast) *used_fast = fast;
     if (fast && p.Bh && EPI != EPI_TANH && EPI != EPI_TANH_STASH) {
         if constexpr (A_KC && B_KC) {
-            if (p.a_amax)
-                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, true, false, EPI>), grid, block, 0, stream, p);
-            else
-                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, false, false, EPI>), grid, block, 0, stream, p);
+            // 128 x 256 tiles (512 threads, one block per CU) pay off for the forward pass only (-4 %; input-grad +3 %)
+            if (g_h3_wide && p.N >= 256 && (EPI == EPI_SINE || EPI == EPI_SINE_STASH)) {
+                p.tiles_n = (p.N + 255) / 256;
+                const dim3 wgrid((unsigned)((long long)p.tiles_m * p.tiles_n * p.splits)), wblock(512);
+                if (p.a_amax)
+                    hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, true, false, EPI, 4>), wgrid, wblock, 0, stream, p);
+                else
+                    hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, false, false, EPI, 4>), wgrid, wblock, 0, stream, p);
+            } else if (p.a_amax) {
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, true, false, EPI, 2>), grid, block, 0, stream, p);
+            } else {
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, false, false, EPI, 2>), grid, block, 0, stream, p);
+            }
             INR_LAUNCH_CHECK();
             return 0;
         }
@@ -851,9 +859,9 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
     if constexpr (!A_KC && !B_KC && EPI == EPI_PLAIN) {
         if (fast && p.a_amax) {
             if (p.b_amax)
-                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, true, EPI>), grid, block, 0, stream, p);
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, true, EPI, 2>), grid, block, 0, stream, p);
             else
-                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, false, EPI>), grid, block, 0, stream, p);
+                hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, false, EPI, 2>), grid, block, 0, stream, p);
             INR_LAUNCH_CHECK();
             return 0;
         }
@@ -936,7 +944,6 @@ static inline void h3_apply(GemmParams& p, const H3Args* h) {
     if (!h) return;
     p.a_amax = h->a_amax; p.b_amax = h->b_amax; p.Bh = h->Bh; p.Bl = h->Bl; p.amax_out = h->amax_out;
     p.reverse_m = h->reverse_m;
-    p.ablate = g_h3_ablate;
 }
 
 int gemm_sine_forward(float* act, float* dact, const float* x, const float* W, const float* b, int64_t n,
