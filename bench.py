@@ -219,6 +219,9 @@ def main():
     from mri_super_resolution_amd._lib import lib as inr_lib
     from oracle import torch_port as P
     inr_lib().inr_debug_set(3, 0 if args.fp32_mfma else 1)
+    for kv in filter(None, os.environ.get("INR_DEBUG_KEYS", "").split(",")):   # e.g. "5=0,6=0": A/B of tuning switches
+        k, v = kv.split("=")
+        inr_lib().inr_debug_set(int(k), int(v))
 
     # ---- workload: one synthetic 128^3 volume per rank (seeded by rank), resident in HBM -------------
     vol = P.synthetic_volume(SIDE, seed=rank)
@@ -279,7 +282,7 @@ def main():
         with open(pmc_path) as fh:
             pm = json.load(fh)
             traffic = pm.get("gemm_f32_avg_hbm_bytes_per_launch" if args.fp32_mfma else "gemm_h3_avg_hbm_bytes_per_launch")
-        traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same command)"
+        traffic_src = "profiles/r01_pmc_hbm.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)"
     # algorithmic HBM bytes of the 11 GEMM launches of one step, in units of one [N,512] fp32 matrix:
     # forward 0.5+2 (layer 0) + 3*(1+2); input-grad 3*(1+1+1); param-grad 1.5 (layer 0) + 3*2  = 28 matrices
     algo_bytes = 28.0 * n_lr * HIDDEN * 4 / 11.0
