@@ -65,7 +65,7 @@ int input_grad_colsum_rows(int64_t n);
 int gemm_input_grad(float* dz_prev, const float* dz, const float* W, const float* mul, int64_t n, int in_f,
                     int out_f, float* colsum_slab, int* slab_rows, hipStream_t stream, const H3Args* h3 = nullptr);
 size_t h3_planes_bytes(long long weights);
-int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream);
+int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream, unsigned floor_bits = 0);
 int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, _Float16* planes,
                     unsigned* amax, unsigned* zero_slots, int n_zero, hipStream_t stream);
 int param_grad_splits(int64_t n, int in_f, int out_f);
@@ -492,7 +492,7 @@ static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const 
     const float* cur = x;
     float* bufs[2] = {buf0, buf1};
     if (h3 && h3->on) {
-        if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st)) return rc;
+        if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
     for (int l = 0; l < L.n_sine; ++l) {
         float* dst = bufs[l & 1];
@@ -706,7 +706,7 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
     H3Ctx h3;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, base + c.h3_off);
-        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], st)) return rc;
+        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
     for (int it = 0; it < n_steps; ++it) {
         if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
@@ -745,7 +745,7 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
     H3Ctx h3;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, base + c.h3_off);
-        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream)) return rc;
+        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream, 0x3f800000u)) return rc;
     }
     return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
                                 (hipStream_t)stream, &h3);

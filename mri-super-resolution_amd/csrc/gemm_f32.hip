@@ -911,8 +911,11 @@ int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, in
     return 0;
 }
 
-int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream) {
-    INR_HIP(hipMemsetAsync(out, 0, sizeof(unsigned), stream));
+// floor_bits: the slot starts from this value (float bits).  The network input uses 1.0f: any tensor within [-1, 1]
+// (Fourier features) then gets the same scale whatever its actual maximum, so a voxel's value cannot depend on which
+// rows happen to share its re-sampling chunk.
+int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t stream, unsigned floor_bits) {
+    INR_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), (int)floor_bits, 1, stream));
     ProfScope ps(KC_OTHER, stream);
     hipLaunchKernelGGL(tensor_amax_kernel, dim3(1024), dim3(256), 0, stream, out, x, n);
     INR_LAUNCH_CHECK();
@@ -934,7 +937,7 @@ static int h3_debug_prepare(H3Args& h, const float* W, int out_f, int in_f, bool
         h.b_amax = slots;
     }
     if (scaled_a) {
-        if (int rc = h3_tensor_amax(slots + 1, scaled_a, a_elems, stream)) return rc;
+        if (int rc = h3_tensor_amax(slots + 1, scaled_a, a_elems, stream, 0u)) return rc;
         h.a_amax = slots + 1;
     }
     return 0;
