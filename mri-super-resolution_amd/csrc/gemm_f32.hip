@@ -840,7 +840,9 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
     if (fast && p.Bh && EPI != EPI_TANH && EPI != EPI_TANH_STASH) {
         if constexpr (A_KC && B_KC) {
             // 128 x 256 tiles (512 threads, one block per CU) pay off for the forward pass only (-4 %; input-grad +3 %)
-            if (g_h3_wide && p.N >= 256 && (EPI == EPI_SINE || EPI == EPI_SINE_STASH)) {
+            // ... and only when the wide grid still covers the chip twice over (small row counts keep the narrow tiles)
+            if (g_h3_wide && p.N >= 256 && (EPI == EPI_SINE || EPI == EPI_SINE_STASH) &&
+                (long long)p.tiles_m * ((p.N + 255) / 256) >= 512) {
                 p.tiles_n = (p.N + 255) / 256;
                 const dim3 wgrid((unsigned)((long long)p.tiles_m * p.tiles_n * p.splits)), wblock(512);
                 if (p.a_amax)
