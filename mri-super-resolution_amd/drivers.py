@@ -23,7 +23,7 @@ import torch
 
 from . import dist as inr_dist
 from . import metrics
-from .inr import ImageFitting_set, Siren, SirenFitter, input_mapping, reconstruct
+from .inr import ImageFitting_set, ShardedSirenFitter, Siren, SirenFitter, input_mapping, reconstruct
 
 
 def load_mat_volume(path: str, key: Optional[str] = None) -> np.ndarray:
@@ -47,12 +47,15 @@ def fourier_matrix(dim: int, mapping_size: int = 128, scale: float = 0.5, seed: 
 def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512, hidden_layers: int = 3,
                mapping_size: int = 128, ff_scale: float = 0.5, lr: float = 1e-4, seed: Optional[int] = 0,
                downsample: bool = True, upscale_axes: int = 2, evaluate: bool = True, chunk_steps: int = 250,
-               return_recon: bool = True, normalize: bool = True) -> Dict[str, object]:
+               return_recon: bool = True, normalize: bool = True, group=None) -> Dict[str, object]:
     """One INR super-resolution fit of an N-D volume (first ``upscale_axes`` axes are in-plane).
 
     ``downsample=True``: the volume is the HR ground truth, training uses ``vol[::2, ::2, ...]`` and the result is
     evaluated on the HR grid (PSNR, mean per-slice SSIM by the reference protocol) as well as re-sampled at 2x the
     HR in-plane size.  ``downsample=False``: the volume itself is the training grid and is re-sampled at 2x.
+    ``group``: a process group whose ranks fit this ONE volume together, each on its contiguous share of the rows
+    (``ShardedSirenFitter``); every member ends with identical weights, only the group's first rank re-samples and
+    evaluates (the others return timings and the final loss).
     """
     vol = np.ascontiguousarray(volume, dtype=np.float32)
     vmax = float(vol.max()) if normalize else 1.0       # superresHybrid normalises per (b, TE) before stacking (:57-63)
@@ -67,18 +70,30 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
     model = Siren(2 * mapping_size, hidden_features, hidden_layers, 1).cuda()
     data = ImageFitting_set([lr_vol])
     model_input = input_mapping(data.coords[0], B)                        # built once per fit (superresDWI.py:122)
+    pixels = data.pixels[0]
+    g_size = torch.distributed.get_world_size(group) if group is not None else 1
+    g_rank = torch.distributed.get_rank(group) if group is not None else 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fitter = SirenFitter(model, lr=lr)
+    if g_size > 1:
+        n_rows = model_input.shape[0]
+        lo, hi = n_rows * g_rank // g_size, n_rows * (g_rank + 1) // g_size
+        model_input, pixels = model_input[lo:hi].contiguous(), pixels[lo:hi].contiguous()
+        fitter = ShardedSirenFitter(model, global_rows=n_rows, lr=lr, group=group)
+    else:
+        fitter = SirenFitter(model, lr=lr)
     losses = []
     done = 0
     while done < steps:
         k = min(chunk_steps, steps - done)
-        losses.append(fitter.step(model_input, data.pixels[0], k))
+        losses.append(fitter.step(model_input, pixels, k))
         done += k
     torch.cuda.synchronize()
     t_fit = time.perf_counter() - t0
     fitter.release_workspace()
+    if g_rank != 0:      # a partner of a sharded fit: the group's first rank owns re-sampling and evaluation
+        return {"n_coords": int(lr_vol.size), "steps": int(steps), "t_fit": t_fit, "t_recon": 0.0,
+                "final_loss": float(torch.cat(losses)[-1]) if steps else None, "model": model, "B": B, "partner": True}
     t0 = time.perf_counter()
     recon = reconstruct(model, test_shape, B)                            # superresDWI.py:125-126,161
     torch.cuda.synchronize()
@@ -189,19 +204,35 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
             "t_recon": t_recon, "t_hybrid_fit": t_hybrid, "final_losses": losses, "slice_index": k}
 
 
-def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, **fit_kwargs) -> List[Dict[str, float]]:
-    """Fits every volume once, partitioned over the ranks of the current process group (LPT on coordinate count);
-    returns the gathered per-fit metric records on every rank (one RCCL all_gather)."""
+def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True,
+                **fit_kwargs) -> List[Dict[str, float]]:
+    """Fits every volume once over the ranks of the current process group and returns the gathered per-fit metric
+    records on every rank (one RCCL all_gather).  Schedule: ``dist.plan_fits`` -- the volumes that do not fill a whole
+    round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
+    ``allow_sharding=False`` is plain LPT packing (no collective on the data path at all)."""
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     costs = [float(np.prod([s // 2 if a < 2 else s for a, s in enumerate(v.shape)])) * steps for v in volumes]
-    plan = inr_dist.partition_fits(costs, world)
+    if allow_sharding and world > 1:
+        plan = inr_dist.plan_fits(costs, world)
+    else:
+        plan = {"gangs": [], "whole": inr_dist.partition_fits(costs, world)}
     local = []
-    for job in plan[rank]:
-        res = fit_volume(volumes[job], steps=steps, return_recon=False, **fit_kwargs)
+
+    def record(job, res):
         local.append({"job": job, "n_coords": res["n_coords"], "steps": steps, "t_fit": res["t_fit"],
                       "t_recon": res["t_recon"], "psnr_db": res.get("psnr_db", float("nan")),
                       "ssim_mean": res.get("ssim_mean", float("nan")), "final_loss": res["final_loss"]})
-    max_jobs = max(len(p) for p in plan) if plan else 0
-    records = inr_dist.gather_job_records(local, RECORD_KEYS, max(max_jobs, 1))
+
+    # gang phase: every rank creates every group (new_group is collective over the default group), then works in its own
+    groups = [(job, ranks, torch.distributed.new_group(ranks) if len(ranks) > 1 else None) for job, ranks in plan["gangs"]]
+    for job, ranks, grp in groups:
+        if rank in ranks:
+            res = fit_volume(volumes[job], steps=steps, return_recon=False, group=grp, **fit_kwargs)
+            if not res.get("partner"):
+                record(job, res)
+    for job in plan["whole"][rank]:
+        record(job, fit_volume(volumes[job], steps=steps, return_recon=False, **fit_kwargs))
+    max_jobs = max((len(p) for p in plan["whole"]), default=0) + 1
+    records = inr_dist.gather_job_records(local, RECORD_KEYS, max_jobs)
     return sorted(records, key=lambda r: r["job"])

@@ -26,6 +26,33 @@ def test_lpt_partition_properties():
         inr_dist.partition_fits(costs, 0)
 
 
+def test_gang_sharded_plan_properties():
+    """plan_fits: the volumes that do not fill a whole round are row-sharded over disjoint rank groups that start
+    together; every job runs exactly once; the reference's 11 patients reach 7.5x on 8 ranks (6.04x whole-volume)."""
+    costs = [64 * 64 * z for z in (28, 28, 28, 28, 28, 24, 24, 24, 34, 34, 34)]
+    plan = inr_dist.plan_fits(costs, 8)
+    gang_jobs = [j for j, _ in plan["gangs"]]
+    whole_jobs = [j for jobs in plan["whole"] for j in jobs]
+    assert sorted(gang_jobs + whole_jobs) == list(range(11))
+    ranks = [r for _, rs in plan["gangs"] for r in rs]
+    assert sorted(ranks) == list(range(8)) and all(rs == list(range(rs[0], rs[0] + len(rs))) for _, rs in plan["gangs"])
+    assert sorted(gang_jobs) == [8, 9, 10]                                   # the three 34-slice volumes, over 3 + 3 + 2 ranks
+    assert sum(costs) / plan["makespan"] > 7.5
+    assert plan == inr_dist.plan_fits(costs, 8)                               # deterministic
+    # never worse than whole-volume packing, which it falls back to when nothing is gained
+    for cs, w in (([1.0] * 8, 8), ([1.0] * 16, 8), ([3, 1, 1, 1], 2), ([2.0], 1), ([], 4)):
+        p = inr_dist.plan_fits(cs, w)
+        assert p["gangs"] == [] and p["makespan"] == inr_dist.makespan(cs, inr_dist.partition_fits(cs, w))
+    # one dominant volume: split it
+    p = inr_dist.plan_fits([5.0, 1.0], 2)
+    assert p["gangs"] == [(0, [0, 1])] and p["makespan"] == pytest.approx(2.5 * 1.03 + 1.0)
+    # fewer volumes than ranks: everything sharded, groups in proportion to the work
+    p = inr_dist.plan_fits([2.0, 1.0, 1.0], 8)
+    assert [len(r) for _, r in p["gangs"]] == [4, 2, 2] and all(not w for w in p["whole"])
+    assert inr_dist._split_ranks(5, [1, 1, 1, 1, 1]) == [[0], [1], [2], [3], [4]]
+    assert [len(g) for g in inr_dist._split_ranks(8, [10, 1, 1])] == [6, 1, 1]
+
+
 def test_gather_single_process():
     rec = {"n": 4096.0, "seconds": 1.5}
     assert inr_dist.gather_records(rec) == [rec]

@@ -88,3 +88,54 @@ def test_two_rank_fit_matches_single_process():
     assert np.array_equal(f0, f1)                                # identical replicas after identical Adam steps
     assert np.allclose(l0, l1) and np.allclose(l0, ref_losses, rtol=1e-5)
     assert O.rel_l2(f0, ref_flat) < 1e-5
+
+
+def _volumes():
+    rng = np.random.default_rng(3)
+    gx, gy = np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 20), indexing="ij")
+    base = 0.4 + 0.3 * np.sin(4 * gx) * np.cos(3 * gy)
+    # three volumes on two ranks: the 5-slice one is the odd one out and gets row-sharded over both ranks
+    return [np.stack([base * (1 + 0.1 * k) for k in range(z)], axis=-1).astype(np.float32) + 0.01 * rng.random((24, 20, z)).astype(np.float32)
+            for z in (2, 5, 2)]
+
+
+def _run_volumes_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mri_super_resolution_amd import drivers
+        recs = drivers.run_volumes(_volumes(), steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=0,
+                                   chunk_steps=10)
+        q.put((rank, recs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_volumes_with_a_row_sharded_fit():
+    """drivers.run_volumes on 2 ranks (gloo, both on the one test GPU): the plan shards the largest volume over both
+    ranks and packs the other two whole; every rank gets the same three records, and they match single-process fits."""
+    from mri_super_resolution_amd import dist as inr_dist
+    from mri_super_resolution_amd import drivers
+    vols = _volumes()
+    costs = [float(v.shape[0] // 2 * (v.shape[1] // 2) * v.shape[2]) * 40 for v in vols]
+    plan = inr_dist.plan_fits(costs, 2)
+    assert plan["gangs"] == [(1, [0, 1])] and sorted(j for w in plan["whole"] for j in w) == [0, 2]
+    want = [drivers.fit_volume(v, steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=0, chunk_steps=10,
+                               return_recon=False) for v in vols]
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_volumes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get() for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    recs0, recs1 = results[0][1], results[1][1]
+    assert recs0 == recs1 and [int(r["job"]) for r in recs0] == [0, 1, 2]
+    for rec, ref in zip(recs0, want):
+        assert rec["n_coords"] == ref["n_coords"]
+        assert rec["final_loss"] == pytest.approx(ref["final_loss"], rel=2e-3)     # sharded: another summation order
+        assert rec["psnr_db"] == pytest.approx(ref["psnr_db"], abs=0.05)
