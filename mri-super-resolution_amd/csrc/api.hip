@@ -92,6 +92,11 @@ bool head_fused_ok(int hidden, int out_f, const void* a, const void* b, const vo
 int64_t head_fused_blocks(int64_t n);
 int launch_head_bwd_fused(float* dz, float* slab_b, float* slab_w, const float* gy, const float* W, const float* a,
                           const float* dact, int64_t n, int hidden, hipStream_t st, unsigned* amax_out = nullptr);
+bool head_step_fused_ok(int hidden, int out_f, const void* a, const void* b, const void* c, const void* d);
+int launch_head_step_fused(float* dz, float* slab_b, float* slab_w, float* part_loss, float* part_g, const float* a,
+                           const float* dact, const float* W, const float* bias, const float* t, const float* wgt,
+                           int64_t n, int hidden, int64_t count_total, hipStream_t st, unsigned* amax_out);
+int launch_finish_sum(float* out, const float* partial, int nparts, float scale, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int64_t step, double lr, double b1,
                 double b2, double eps, hipStream_t st);
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
@@ -274,7 +279,7 @@ static H3Args h3_param_grad_args(const H3Ctx& c, int l) {
 
 static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
     const int64_t blocks = head_fused_blocks(n);
-    const size_t fused = (size_t)(2 * blocks * hidden + reduce_tmp_floats(blocks, hidden));
+    const size_t fused = (size_t)(2 * blocks * hidden + reduce_tmp_floats(blocks, hidden) + 2 * blocks);   // + loss / sum-g partials
     const size_t a = (size_t)colsum_ws_floats(n, hidden, out_f);
     const size_t b = (size_t)colsum_ws_floats(n, out_f, 1);
     return max2(fused, max2(a, b));
@@ -627,18 +632,36 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
                                        L.fan_in[l], L.fan_out[l], omega, st, split ? &ha : nullptr))
             return rc;
     }
-    if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
-                                     0.f, st))
-        return rc;
-    // loss + dL/dy (superresDWI.py:135)
-    if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st, count_total)) return rc;
-    // backward: head, then sine layers from last to first; dz overwrites dact in place
-    // (bias gradients ride along: the head pass yields gb of the last sine layer, every input-grad GEMM
-    //  yields gb of the layer below from its epilogue)
-    if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
-                               grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
-                               H, O, scratch, st, split ? h3->slots + 8 + head - 1 : nullptr))
-        return rc;
+    // head forward, loss + dL/dy (superresDWI.py:135), head backward; then the sine layers from last to first, dz
+    // overwriting dact in place (bias gradients ride along: the head pass yields gb of the last sine layer, every
+    // input-grad GEMM yields gb of the layer below from its epilogue)
+    if (head_step_fused_ok(H, O, act[head], dact[head - 1], params + L.w_off[head], scratch)) {
+        // one pass over act_L / dact_L does all three (kernels.hip: head_step_fused_kernel)
+        const int64_t blocks = head_fused_blocks(n);
+        float* slab_b = scratch;
+        float* slab_w = scratch + blocks * H;
+        float* tmp = scratch + 2 * blocks * H;
+        float* part_loss = tmp + reduce_tmp_floats(blocks, H);
+        float* part_g = part_loss + blocks;
+        if (int rc = launch_head_step_fused(dact[head - 1], slab_b, slab_w, part_loss, part_g, act[head], dact[head - 1],
+                                            params + L.w_off[head], params + L.b_off[head], target, weight, n, H,
+                                            count_total, st, split ? h3->slots + 8 + head - 1 : nullptr))
+            return rc;
+        if (int rc = launch_reduce_slabs(grads + L.b_off[head - 1], slab_b, (int)blocks, H, tmp, st)) return rc;
+        if (int rc = launch_reduce_slabs(grads + L.w_off[head], slab_w, (int)blocks, H, tmp, st)) return rc;
+        const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
+        if (int rc = launch_finish_sum(loss_dst, part_loss, (int)blocks, inv, st)) return rc;
+        if (int rc = launch_finish_sum(grads + L.b_off[head], part_g, (int)blocks, 1.0f, st)) return rc;
+    } else {
+        if (int rc = launch_head_forward(y, act[head], params + L.w_off[head], params + L.b_off[head], n, H, O, 0,
+                                         0.f, st))
+            return rc;
+        if (int rc = launch_mse(gy, loss_dst, y, target, weight, n * O, scratch + 1, st, count_total)) return rc;
+        if (int rc = head_backward(dact[head - 1], grads + L.w_off[head], grads + L.b_off[head],
+                                   grads + L.b_off[head - 1], gy, act[head], dact[head - 1], params + L.w_off[head], n,
+                                   H, O, scratch, st, split ? h3->slots + 8 + head - 1 : nullptr))
+            return rc;
+    }
     for (int l = L.n_sine - 1; l >= 0; --l) {
         H3Args hp, hi;
         if (split) {
