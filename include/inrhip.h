@@ -244,6 +244,14 @@ int inr_rams_forward(const inr_rams_desc_t* desc, const float* params, const flo
 size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border);
 int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int n_images, int size,
                         int border, int mode, void* workspace, size_t workspace_bytes, void* stream);
+/* the loss half of `Trainer.train_step` (utils/training.py:193-209): loss[b] = cL1 as above and grad_pred[b] =
+ * upstream[b] * d loss[b] / d y_pred[b] ([n_images][size][size] fp32, zero on the `border` frame), taken through the
+ * best shift as TensorFlow's reduce_min does; upstream nullable (= 1: the gradient of sum_b loss[b], what
+ * tape.gradient of the loss vector returns). */
+size_t inr_rams_shift_loss_grad_workspace_bytes(int n_images, int border);
+int inr_rams_shift_loss_grad(double* loss, float* grad_pred, const float* y_true, const float* y_pred, const float* mask,
+                             const float* upstream, int n_images, int size, int border, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- (f)-1: three-compartment hybrid fit (PIA.py:240-283 `three_compartment_fit` / `hybrid_fit`, called at
  * superresHybrid.py:140).  signals: [n_voxels][16] fp64, b-major over b = {0,150,1000,1500} x TE = {0,13,93,143}

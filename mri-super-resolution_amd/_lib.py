@@ -96,6 +96,9 @@ SIGNATURES = {
     "inr_rams_shift_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "inr_rams_shift_loss": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, c_stream]),
+    "inr_rams_shift_loss_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "inr_rams_shift_loss_grad": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_size_t, c_stream]),
     "inr_hybrid_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_stream]),
     "inr_prof_enable": (C.c_int, [C.c_int]),
     "inr_prof_reset": (C.c_int, []),

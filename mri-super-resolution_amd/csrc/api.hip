@@ -110,6 +110,8 @@ int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, 
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st);
 void set_hybrid_variant(int v);
+int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const float* y_pred, const float* mask,
+                           const float* upstream, int nimg, int size, int border, double* ws, hipStream_t st);
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
                       int border, int mode, double* ws, hipStream_t st);
 long long rams_param_floats(const inr_rams_desc_t* d);
@@ -827,6 +829,23 @@ int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, c
                 "inr_rams_shift_loss: workspace too small");
     return launch_shift_loss(out, y_true, y_pred, mask, n_images, size, border, mode, (double*)workspace,
                              (hipStream_t)stream);
+}
+
+size_t inr_rams_shift_loss_grad_workspace_bytes(int n_images, int border) {
+    return inr_rams_shift_loss_workspace_bytes(n_images, border) + (size_t)(n_images > 0 ? n_images : 1) * sizeof(int) + 8;
+}
+
+int inr_rams_shift_loss_grad(double* loss, float* grad_pred, const float* y_true, const float* y_pred, const float* mask,
+                             const float* upstream, int n_images, int size, int border, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(loss && grad_pred && y_true && y_pred && mask, INR_E_INVALID, "inr_rams_shift_loss_grad: null pointer");
+    INR_REQUIRE(n_images >= 1 && n_images <= 65535 && border >= 0 && border <= 16 && size > 2 * border, INR_E_INVALID,
+                "inr_rams_shift_loss_grad: bad arguments (size=%d border=%d)", size, border);
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_shift_loss_grad_workspace_bytes(n_images, border), INR_E_WORKSPACE,
+                "inr_rams_shift_loss_grad: workspace too small");
+    INR_REQUIRE(((uintptr_t)workspace & 7) == 0, INR_E_ALIGN, "inr_rams_shift_loss_grad: workspace must be 8-byte aligned");
+    return launch_shift_loss_grad(loss, grad_pred, y_true, y_pred, mask, upstream, n_images, size, border, (double*)workspace,
+                                  (hipStream_t)stream);
 }
 
 int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream) {

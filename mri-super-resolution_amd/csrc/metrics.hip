@@ -162,17 +162,70 @@ __global__ void __launch_bounds__(256) shift_loss_kernel(double* __restrict__ pe
 }
 
 // out[b] = min over shifts of cL1 (mode 0) / max over shifts of 10*log10(65535^2 / cMSE) (mode 1)
-__global__ void shift_loss_finish_kernel(double* __restrict__ out, const double* __restrict__ per_shift, int nshift2,
-                                         int mode, int nimg) {
+__global__ void shift_loss_finish_kernel(double* __restrict__ out, int* __restrict__ arg, const double* __restrict__ per_shift,
+                                         int nshift2, int mode, int nimg) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nimg) return;
     double best = 0.0;
-    for (int k = 0; k < nshift2; ++k) {
+    int at = 0;
+    for (int k = 0; k < nshift2; ++k) {   // first best shift wins ties (tf.reduce_min / reduce_max pass the gradient to ... see below)
         const double v = per_shift[(long long)b * nshift2 + k];
         const double val = mode == 0 ? v : 10.0 * log10(65535.0 * 65535.0 / v);
-        if (k == 0 || (mode == 0 ? val < best : val > best)) best = val;
+        if (k == 0 || (mode == 0 ? val < best : val > best)) {
+            best = val;
+            at = k;
+        }
     }
     out[b] = best;
+    if (arg) arg[b] = at;
+}
+
+// Gradient of the cL1 loss of utils/loss.py:26-75 with respect to the prediction, through the best shift (i*, j*) = arg:
+// with d_p = m_p lab_p - m_p (m_p pred_p + b), b = (1/T) sum_p m_p (lab_p - pred_p), T = sum_p m_p, s_p = sign(d_p):
+//   dL/dpred_q = (1/T) [ -s_q m_q^2 + (m_q / T) sum_p s_p m_p ]      inside the cropped window, 0 on the border.
+// (Exact ties between shifts split the gradient in TensorFlow; here the first best shift takes it all -- ties have
+// measure zero on real data.)  One block per image, three passes over the window, fp64 accumulation.
+__global__ void __launch_bounds__(256) shift_loss_grad_kernel(float* __restrict__ grad, const float* __restrict__ y_true,
+                                                              const float* __restrict__ y_pred, const float* __restrict__ mask,
+                                                              const int* __restrict__ arg, int size, int border,
+                                                              const float* __restrict__ upstream) {
+    __shared__ double red[4];
+    const int b = blockIdx.x, nshift = 2 * border + 1, c = size - 2 * border;
+    const int si = arg[b] / nshift, sj = arg[b] % nshift;
+    const float* yt = y_true + (long long)b * size * size;
+    const float* yp = y_pred + (long long)b * size * size;
+    const float* mk = mask + (long long)b * size * size;
+    float* gr = grad + (long long)b * size * size;
+    for (int i = threadIdx.x; i < size * size; i += 256) gr[i] = 0.f;
+    double sm = 0.0, sd = 0.0;
+    for (int i = threadIdx.x; i < c * c; i += 256) {
+        const int r = i / c, q = i - r * c;
+        const double m = mk[(long long)(si + r) * size + sj + q];
+        sm += m;
+        sd += m * ((double)yt[(long long)(si + r) * size + sj + q] - (double)yp[(long long)(border + r) * size + border + q]);
+    }
+    sm = block_sum_f64(sm, red);
+    sd = block_sum_f64(sd, red);
+    const double bias = sd / sm;
+    double ssm = 0.0;
+    for (int i = threadIdx.x; i < c * c; i += 256) {
+        const int r = i / c, q = i - r * c;
+        const double m = mk[(long long)(si + r) * size + sj + q];
+        const double d = m * (double)yt[(long long)(si + r) * size + sj + q] -
+                         m * (m * (double)yp[(long long)(border + r) * size + border + q] + bias);
+        ssm += (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0)) * m;
+    }
+    ssm = block_sum_f64(ssm, red);
+    const double up = upstream ? (double)upstream[b] : 1.0;
+    __syncthreads();   // the zero fill above is complete
+    for (int i = threadIdx.x; i < c * c; i += 256) {
+        const int r = i / c, q = i - r * c;
+        const double m = mk[(long long)(si + r) * size + sj + q];
+        const double d = m * (double)yt[(long long)(si + r) * size + sj + q] -
+                         m * (m * (double)yp[(long long)(border + r) * size + border + q] + bias);
+        const double s = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0);
+        gr[(long long)(border + r) * size + border + q] = (float)(up * (-s * m * m + m / sm * ssm) / sm);
+    }
 }
 
 constexpr int METRIC_BLOCKS = 64;
@@ -210,7 +263,24 @@ int launch_shift_loss(double* out, const float* y_true, const float* y_pred, con
     ProfScope ps(KC_OTHER, st);
     hipLaunchKernelGGL(shift_loss_kernel, dim3(ns * ns, nimg), dim3(256), 0, st, ws, y_true, y_pred, mask, size, border, mode);
     INR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(shift_loss_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, ws, ns * ns, mode, nimg);
+    hipLaunchKernelGGL(shift_loss_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, out, (int*)nullptr, ws, ns * ns, mode,
+                       nimg);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss (cL1, per image) and its gradient with respect to y_pred; ws: nimg * (2*border+1)^2 doubles + nimg ints
+int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const float* y_pred, const float* mask,
+                           const float* upstream, int nimg, int size, int border, double* ws, hipStream_t st) {
+    const int ns = 2 * border + 1;
+    int* arg = reinterpret_cast<int*>(ws + (size_t)nimg * ns * ns);
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(shift_loss_kernel, dim3(ns * ns, nimg), dim3(256), 0, st, ws, y_true, y_pred, mask, size, border, 0);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(shift_loss_finish_kernel, dim3((nimg + 63) / 64), dim3(64), 0, st, loss, arg, ws, ns * ns, 0, nimg);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(shift_loss_grad_kernel, dim3(nimg), dim3(256), 0, st, grad, y_true, y_pred, mask, arg, size, border,
+                       upstream);
     INR_LAUNCH_CHECK();
     return 0;
 }

@@ -180,3 +180,28 @@ def l1_loss(y_true, y_pred, y_mask, HR_SIZE=384):
 def psnr(y_true, y_pred, y_mask, size_image=384):
     """utils/loss.py:77-127: mean over the batch of the maximum cPSNR over the 7x7 shifts (data range 65535)."""
     return _shift_loss(y_true, y_pred, y_mask, size_image, 1).mean()
+
+
+def l1_loss_and_grad(y_true, y_pred, y_mask, HR_SIZE=384, upstream=None):
+    """The loss half of ``Trainer.train_step`` (utils/training.py:193-209): per-image cL1 (utils/loss.py:26-75) and the
+    gradient of ``sum_b upstream[b] * loss[b]`` with respect to ``y_pred`` ([B, S, S] fp32), through the best shift."""
+    dev = ops.require_gpu()
+
+    def prep(t):
+        t = torch.as_tensor(np.asarray(t, np.float32) if not torch.is_tensor(t) else t).to(dev, torch.float32)
+        if t.dim() == 4 and t.shape[-1] == 1:
+            t = t[..., 0]
+        if t.dim() != 3 or t.shape[1] != HR_SIZE or t.shape[2] != HR_SIZE:
+            raise ValueError(f"expected [B, {HR_SIZE}, {HR_SIZE}(, 1)], got {tuple(t.shape)}")
+        return t.contiguous()
+
+    yt, yp, mk = prep(y_true), prep(y_pred), prep(y_mask)
+    B = yt.shape[0]
+    up = None if upstream is None else torch.as_tensor(upstream, dtype=torch.float32, device=dev).contiguous()
+    loss = torch.empty(B, dtype=torch.float64, device=dev)
+    grad = torch.empty_like(yp)
+    ws = torch.empty((lib().inr_rams_shift_loss_grad_workspace_bytes(B, 3) + 7) // 8, dtype=torch.float64, device=dev)
+    check(lib().inr_rams_shift_loss_grad(loss.data_ptr(), grad.data_ptr(), yt.data_ptr(), yp.data_ptr(), mk.data_ptr(),
+                                         0 if up is None else up.data_ptr(), B, int(HR_SIZE), 3, ws.data_ptr(), ws.numel() * 8,
+                                         ops._stream()), "inr_rams_shift_loss_grad")
+    return loss, grad

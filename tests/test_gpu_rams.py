@@ -78,3 +78,36 @@ def test_shift_tolerant_losses_match_oracle():
     # the planted shift (+1, -2 relative to the centre (3,3)) is the best one: loss far below the unshifted one
     unshifted = np.abs((y_true - y_pred)[:, 3:-3, 3:-3]).mean()
     assert (got_l1 < 0.5 * unshifted).all()
+
+
+def test_shift_loss_gradient_matches_autograd():
+    """d cL1 / d prediction through the best shift (the loss half of train_step) against torch autograd on a float64
+    restatement of utils/loss.py:26-75."""
+    rng = np.random.default_rng(11)
+    B, size = 3, 40
+    y_true = (rng.random((B, size, size)) * 30000 + 5000).astype(np.float32)
+    y_pred = (np.roll(y_true, (-1, 2), axis=(1, 2)) * 1.02 - 90 + rng.standard_normal((B, size, size)) * 40).astype(np.float32)
+    mask = (rng.random((B, size, size)) > 0.2).astype(np.float32)
+    up = np.array([1.0, 0.5, 2.0], np.float32)
+
+    yt, mk = torch.from_numpy(y_true).double(), torch.from_numpy(mask).double()
+    yp = torch.from_numpy(y_pred).double().requires_grad_(True)
+    c = size - 6
+    pred = yp[:, 3:size - 3, 3:size - 3]
+    per = []
+    for i in range(7):
+        for j in range(7):
+            lab, m = yt[:, i:i + c, j:j + c], mk[:, i:i + c, j:j + c]
+            tot = m.sum(dim=(1, 2))
+            b = ((lab * m - pred * m).sum(dim=(1, 2)) / tot)[:, None, None]
+            per.append((lab * m - (pred * m + b) * m).abs().sum(dim=(1, 2)) / tot)
+    want_loss = torch.stack(per).min(dim=0).values
+    (want_loss * torch.from_numpy(up).double()).sum().backward()
+
+    loss, grad = rams.l1_loss_and_grad(y_true, y_pred, mask, HR_SIZE=size, upstream=up)
+    assert np.allclose(loss.cpu().numpy(), want_loss.detach().numpy(), rtol=1e-9)
+    g, w = grad.cpu().numpy().astype(np.float64), yp.grad.numpy()
+    assert np.abs(g - w).max() <= 1e-6 * np.abs(w).max()
+    assert np.count_nonzero(g[:, :3]) == 0 and np.count_nonzero(g[:, :, -3:]) == 0       # nothing on the border frame
+    loss1, grad1 = rams.l1_loss_and_grad(y_true, y_pred, mask, HR_SIZE=size)
+    assert torch.equal(loss1, loss) and np.allclose(grad1[1].cpu().numpy() * 0.5, g[1], rtol=1e-6, atol=1e-12)
