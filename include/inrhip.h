@@ -244,6 +244,22 @@ int inr_rams_forward(const inr_rams_desc_t* desc, const float* params, const flo
 size_t inr_rams_shift_loss_workspace_bytes(int n_images, int border);
 int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int n_images, int size,
                         int border, int mode, void* workspace, size_t workspace_bytes, void* stream);
+/* building blocks of the network half of `Trainer.train_step` (utils/training.py:193-209) for the 3x3x3 convolutions
+ * 32 -> 32 that carry >= 99 % of RAMS' work (utils/network.py:29-35).  Layouts as in inr_rams_forward: activations
+ * [B][D1][D2][D3][32] fp32 (NDHWC), folded kernel w[27 taps][32 cin][32 cout], bias[32]; pad 1 = 'same', 0 = 'valid'.
+ *   forward: y = conv(x, w) + bias (+ReLU)                                   -- the inference kernel, on its own
+ *   dgrad  : dx = d loss / d x of a 'same' convolution, given dy             -- the same kernel on the flipped, transposed w
+ *   wgrad  : gw[27][32][32] = d loss / d w, gb[32] = d loss / d bias (nullable) -- MFMA contraction over the voxels,
+ *            fixed-order slab reduction (bitwise reproducible) */
+int inr_rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
+                            int relu, void* stream);
+size_t inr_rams_conv3d_dgrad_workspace_bytes(void);
+int inr_rams_conv3d_dgrad(float* dx, const float* dy, const float* w, int B, int D1, int D2, int D3, void* workspace,
+                          size_t workspace_bytes, void* stream);
+size_t inr_rams_conv3d_wgrad_workspace_bytes(int B, int D1, int D2, int D3, int pad);
+int inr_rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
 /* the loss half of `Trainer.train_step` (utils/training.py:193-209): loss[b] = cL1 as above and grad_pred[b] =
  * upstream[b] * d loss[b] / d y_pred[b] ([n_images][size][size] fp32, zero on the `border` frame), taken through the
  * best shift as TensorFlow's reduce_min does; upstream nullable (= 1: the gradient of sum_b loss[b], what

@@ -96,6 +96,14 @@ SIGNATURES = {
     "inr_rams_shift_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "inr_rams_shift_loss": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, c_stream]),
+    "inr_rams_conv3d_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          c_stream]),
+    "inr_rams_conv3d_dgrad_workspace_bytes": (C.c_size_t, []),
+    "inr_rams_conv3d_dgrad": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                        c_stream]),
+    "inr_rams_conv3d_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "inr_rams_conv3d_wgrad": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_size_t, c_stream]),
     "inr_rams_shift_loss_grad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "inr_rams_shift_loss_grad": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_size_t, c_stream]),

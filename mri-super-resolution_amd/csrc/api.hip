@@ -110,6 +110,12 @@ int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, 
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st);
 void set_hybrid_variant(int v);
+size_t rams_conv3d_wgrad_ws_floats(long long nvox);
+int rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
+                        int relu, hipStream_t st);
+int rams_conv3d_dgrad_same(float* dx, const float* dy, const float* w, int B, int D1, int D2, int D3, float* ws, hipStream_t st);
+int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
+                      hipStream_t st);
 int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const float* y_pred, const float* mask,
                            const float* upstream, int nimg, int size, int border, double* ws, hipStream_t st);
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
@@ -829,6 +835,48 @@ int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, c
                 "inr_rams_shift_loss: workspace too small");
     return launch_shift_loss(out, y_true, y_pred, mask, n_images, size, border, mode, (double*)workspace,
                              (hipStream_t)stream);
+}
+
+static int conv3d_dims_ok(int B, int D1, int D2, int D3, int pad) {
+    INR_REQUIRE(B >= 1 && B <= 65535 && D1 >= 1 && D2 >= 1 && D3 >= 1 && (pad == 0 || pad == 1), INR_E_INVALID,
+                "conv3d: bad shape (B=%d D=%dx%dx%d pad=%d)", B, D1, D2, D3, pad);
+    INR_REQUIRE(D1 + 2 * pad > 2 && D2 + 2 * pad > 2 && D3 + 2 * pad > 2, INR_E_INVALID, "conv3d: volume smaller than the kernel");
+    INR_REQUIRE((long long)B * D1 * D2 * D3 * 32 * 4 < (1ll << 40), INR_E_INVALID, "conv3d: volume too large");
+    return 0;
+}
+
+int inr_rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
+                            int relu, void* stream) {
+    INR_REQUIRE(y && x && w && bias, INR_E_INVALID, "inr_rams_conv3d_forward: null pointer");
+    if (int rc = conv3d_dims_ok(B, D1, D2, D3, pad)) return rc;
+    INR_REQUIRE(aligned16(x) && aligned16(w), INR_E_ALIGN, "inr_rams_conv3d_forward: x / w must be 16-byte aligned");
+    return rams_conv3d_forward(y, x, w, bias, B, D1, D2, D3, pad, relu, (hipStream_t)stream);
+}
+
+size_t inr_rams_conv3d_dgrad_workspace_bytes(void) { return (27 * 32 * 32 + 64) * sizeof(float); }
+
+int inr_rams_conv3d_dgrad(float* dx, const float* dy, const float* w, int B, int D1, int D2, int D3, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(dx && dy && w, INR_E_INVALID, "inr_rams_conv3d_dgrad: null pointer");
+    if (int rc = conv3d_dims_ok(B, D1, D2, D3, 1)) return rc;
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_conv3d_dgrad_workspace_bytes(), INR_E_WORKSPACE,
+                "inr_rams_conv3d_dgrad: workspace too small");
+    INR_REQUIRE(aligned16(dy) && aligned16(workspace), INR_E_ALIGN, "inr_rams_conv3d_dgrad: dy / workspace must be 16-byte aligned");
+    return rams_conv3d_dgrad_same(dx, dy, w, B, D1, D2, D3, (float*)workspace, (hipStream_t)stream);
+}
+
+size_t inr_rams_conv3d_wgrad_workspace_bytes(int B, int D1, int D2, int D3, int pad) {
+    const long long nvox = (long long)B * (D1 + 2 * pad - 2) * (D2 + 2 * pad - 2) * (D3 + 2 * pad - 2);
+    return rams_conv3d_wgrad_ws_floats(nvox > 0 ? nvox : 1) * sizeof(float);
+}
+
+int inr_rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(gw && x && dy, INR_E_INVALID, "inr_rams_conv3d_wgrad: null pointer");
+    if (int rc = conv3d_dims_ok(B, D1, D2, D3, pad)) return rc;
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_conv3d_wgrad_workspace_bytes(B, D1, D2, D3, pad), INR_E_WORKSPACE,
+                "inr_rams_conv3d_wgrad: workspace too small");
+    return rams_conv3d_wgrad(gw, gb, x, dy, B, D1, D2, D3, pad, (float*)workspace, (hipStream_t)stream);
 }
 
 size_t inr_rams_shift_loss_grad_workspace_bytes(int n_images, int border) {

@@ -393,6 +393,132 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
     return 0;
 }
 
+int rams_waves_per_b(int B, int ovox);
+
+// ---- building blocks of the training step (utils/training.py:193-209) -------------------------------
+// data gradient of a 'same' 3x3x3 convolution = the same convolution of dy with the kernel flipped along every axis
+// and its channel axes swapped:  wd[tap'][co][ci] = w[26 - tap'][ci][co]
+__global__ void __launch_bounds__(256) conv3d_dgrad_weights_kernel(float* __restrict__ wd, const float* __restrict__ w) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= CONV_W_FLOATS) return;
+    const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+    wd[i] = w[((26 - tap) * RC + ci) * RC + co];
+}
+
+// weight gradient: gw[tap][ci][co] = sum_v x[v + tap - pad][ci] * dy[v][co] -- an MFMA contraction over the voxels
+// (v_mfma_f32_32x32x2_f32: M = ci, N = co, K = 2 voxels per instruction).  A block walks a contiguous range of output
+// voxels; its 8 waves share the range and split the 27 taps (wave w: taps w, w+8, w+16, w+24), so every wave keeps at
+// most four 32x32 accumulators.  Partial sums go to slab[block][27][32][32] and are reduced in a fixed order.
+struct Conv3dWgradParams {
+    const float* x;    // [B][D1][D2][D3][32]
+    const float* dy;   // [B][O1][O2][O3][32]
+    float* slab;       // [blocks][27][32][32]
+    int B, D1, D2, D3, O1, O2, O3, pad;
+    long long nvox, vox_per_block;
+};
+
+__global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWgradParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+    const long long v0 = (long long)blockIdx.x * p.vox_per_block;
+    const long long v1 = min(p.nvox, v0 + p.vox_per_block);
+    const int ovox = p.O1 * p.O2 * p.O3;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int d1[4], d2[4], d3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tap = wave + 8 * t;   // tap 27..31: idle slot of waves 3..7
+        d1[t] = tap / 9 - p.pad;
+        d2[t] = (tap / 3) % 3 - p.pad;
+        d3[t] = tap % 3 - p.pad;
+    }
+    for (long long vb = v0; vb < v1; vb += 8) {   // 8 voxels = 4 MFMA k-steps; lane half h takes voxels vb + 2 s + h
+        float dyv[4], xv[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long v = vb + 2 * s + h;
+            const bool ok = v < v1;
+            const int b = (int)(v / ovox), o = (int)(v - (long long)b * ovox);
+            const int o3 = o % p.O3, o2 = (o / p.O3) % p.O2, o1 = o / (p.O3 * p.O2);
+            dyv[s] = ok ? p.dy[v * RC + l32] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i1 = o1 + d1[t], i2 = o2 + d2[t], i3 = o3 + d3[t];
+                const bool in = ok && wave + 8 * t < 27 && (unsigned)i1 < (unsigned)p.D1 && (unsigned)i2 < (unsigned)p.D2 &&
+                                (unsigned)i3 < (unsigned)p.D3;
+                xv[t][s] = in ? p.x[((((long long)b * p.D1 + i1) * p.D2 + i2) * p.D3 + i3) * RC + l32] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][s], dyv[s], acc[t], 0, 0, 0);
+    }
+    // C/D map: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 h (ci)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tap = wave + 8 * t;
+        if (tap < 27) {
+            float* dst = p.slab + ((long long)blockIdx.x * 27 + tap) * RC * RC + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * h) * RC] = acc[t][r];
+        }
+    }
+}
+
+constexpr int WGRAD_BLOCKS = 512;
+int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st);
+int64_t colsum_ws_floats(int64_t n, int C, int G);
+int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab, hipStream_t st);
+
+size_t rams_conv3d_wgrad_ws_floats(long long nvox) {
+    const size_t a = (size_t)WGRAD_BLOCKS * CONV_W_FLOATS + (size_t)reduce_tmp_floats(WGRAD_BLOCKS, CONV_W_FLOATS);
+    const size_t b = (size_t)colsum_ws_floats(nvox, RC, 1);
+    return (a > b ? a : b) + 64;
+}
+
+int rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
+                        int relu, hipStream_t st) {
+    const int ovox = (D1 + 2 * pad - 2) * (D2 + 2 * pad - 2) * (D3 + 2 * pad - 2);
+    return conv3d_mfma(x, y, w, bias, nullptr, B, D1, D2, D3, pad, RC, RC, relu, rams_waves_per_b(B, ovox), st);
+}
+
+// dx = conv_same(dy, flip-transpose(w)); ws: 27*32*32 + 32 floats
+int rams_conv3d_dgrad_same(float* dx, const float* dy, const float* w, int B, int D1, int D2, int D3, float* ws,
+                           hipStream_t st) {
+    float* wd = ws;
+    float* zero_bias = ws + CONV_W_FLOATS;
+    INR_HIP(hipMemsetAsync(zero_bias, 0, RC * sizeof(float), st));
+    {
+        ProfScope ps(KC_OTHER, st);
+        hipLaunchKernelGGL(conv3d_dgrad_weights_kernel, dim3((CONV_W_FLOATS + 255) / 256), dim3(256), 0, st, wd, w);
+        INR_LAUNCH_CHECK();
+    }
+    return conv3d_mfma(dy, dx, wd, zero_bias, nullptr, B, D1, D2, D3, 1, RC, RC, 0, rams_waves_per_b(B, D1 * D2 * D3), st);
+}
+
+int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
+                      hipStream_t st) {
+    Conv3dWgradParams p{};
+    p.x = x; p.dy = dy; p.slab = ws;
+    p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3; p.pad = pad;
+    p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
+    p.nvox = (long long)B * p.O1 * p.O2 * p.O3;
+    p.vox_per_block = ((p.nvox + WGRAD_BLOCKS - 1) / WGRAD_BLOCKS + 7) / 8 * 8;
+    {
+        ProfScope ps(KC_OTHER, st);
+        hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(WGRAD_BLOCKS), dim3(512), 0, st, p);
+        INR_LAUNCH_CHECK();
+    }
+    if (int rc = launch_reduce_slabs(gw, ws, WGRAD_BLOCKS, CONV_W_FLOATS, ws + (size_t)WGRAD_BLOCKS * CONV_W_FLOATS, st)) return rc;
+    if (gb) return launch_colsum(gb, dy, nullptr, p.nvox, RC, 1, ws, st);
+    return 0;
+}
+
 // number of waves per batch element for the conv kernel: fill the chip once, never more waves than tiles
 int rams_waves_per_b(int B, int ovox) {
     const int tiles = (ovox + 31) / 32;

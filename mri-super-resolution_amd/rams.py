@@ -205,3 +205,49 @@ def l1_loss_and_grad(y_true, y_pred, y_mask, HR_SIZE=384, upstream=None):
                                          0 if up is None else up.data_ptr(), B, int(HR_SIZE), 3, ws.data_ptr(), ws.numel() * 8,
                                          ops._stream()), "inr_rams_shift_loss_grad")
     return loss, grad
+
+
+# ---- building blocks of the training step: the 3x3x3 convolution 32 -> 32 with its two gradients -----------------------
+def _conv_tensors(x, w, name):
+    dev = ops.require_gpu()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[-1] == 32 and x.is_contiguous()):
+        raise ValueError(f"{name}: activations must be contiguous CUDA float32 [B, D1, D2, D3, 32]")
+    if w is not None and not (w.is_cuda and w.dtype == torch.float32 and tuple(w.shape) == (27, 32, 32) and w.is_contiguous()):
+        raise ValueError(f"{name}: w must be a contiguous CUDA float32 [27, 32, 32] (tap, cin, cout)")
+    return dev
+
+
+def conv3d(x, w, bias, pad=1, relu=False):
+    """y = conv3d(x, w) + bias (optionally ReLU); x [B, D1, D2, D3, 32], w [27, 32, 32] folded kernel, pad 1 = 'same'."""
+    dev = _conv_tensors(x, w, "conv3d")
+    B, D1, D2, D3, _ = x.shape
+    y = torch.empty((B, D1 + 2 * pad - 2, D2 + 2 * pad - 2, D3 + 2 * pad - 2, 32), dtype=torch.float32, device=dev)
+    check(lib().inr_rams_conv3d_forward(y.data_ptr(), x.data_ptr(), w.data_ptr(), bias.contiguous().data_ptr(), B, D1, D2, D3,
+                                        int(pad), 1 if relu else 0, ops._stream()), "inr_rams_conv3d_forward")
+    return y
+
+
+def conv3d_dgrad(dy, w):
+    """d loss / d x of a 'same' convolution: the forward kernel on the flipped, channel-transposed kernel."""
+    dev = _conv_tensors(dy, w, "conv3d_dgrad")
+    B, D1, D2, D3, _ = dy.shape
+    dx = torch.empty_like(dy)
+    ws = torch.empty(lib().inr_rams_conv3d_dgrad_workspace_bytes() // 4, dtype=torch.float32, device=dev)
+    check(lib().inr_rams_conv3d_dgrad(dx.data_ptr(), dy.data_ptr(), w.data_ptr(), B, D1, D2, D3, ws.data_ptr(), ws.numel() * 4,
+                                      ops._stream()), "inr_rams_conv3d_dgrad")
+    return dx
+
+
+def conv3d_wgrad(x, dy, pad=1):
+    """(d loss / d w [27, 32, 32], d loss / d bias [32]) of y = conv3d(x, w) + bias given dy."""
+    dev = _conv_tensors(x, None, "conv3d_wgrad")
+    _conv_tensors(dy, None, "conv3d_wgrad")
+    B, D1, D2, D3, _ = x.shape
+    if tuple(dy.shape) != (B, D1 + 2 * pad - 2, D2 + 2 * pad - 2, D3 + 2 * pad - 2, 32):
+        raise ValueError("conv3d_wgrad: dy does not have the output shape of this convolution")
+    gw = torch.empty((27, 32, 32), dtype=torch.float32, device=dev)
+    gb = torch.empty(32, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib().inr_rams_conv3d_wgrad_workspace_bytes(B, D1, D2, D3, int(pad)) // 4 + 4, dtype=torch.float32, device=dev)
+    check(lib().inr_rams_conv3d_wgrad(gw.data_ptr(), gb.data_ptr(), x.data_ptr(), dy.data_ptr(), B, D1, D2, D3, int(pad),
+                                      ws.data_ptr(), ws.numel() * 4, ops._stream()), "inr_rams_conv3d_wgrad")
+    return gw, gb

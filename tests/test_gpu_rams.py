@@ -111,3 +111,33 @@ def test_shift_loss_gradient_matches_autograd():
     assert np.count_nonzero(g[:, :3]) == 0 and np.count_nonzero(g[:, :, -3:]) == 0       # nothing on the border frame
     loss1, grad1 = rams.l1_loss_and_grad(y_true, y_pred, mask, HR_SIZE=size)
     assert torch.equal(loss1, loss) and np.allclose(grad1[1].cpu().numpy() * 0.5, g[1], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 10, 9, 5), 1), ((1, 7, 8, 9), 0), ((3, 12, 6, 3), 1)])
+def test_conv3d_forward_and_gradients_vs_torch(shape, pad):
+    """The 3x3x3 convolution 32 -> 32 on its own, its data gradient ('same') and its weight / bias gradients against
+    torch's conv3d + autograd in float64."""
+    import torch.nn.functional as F
+    B, D1, D2, D3 = shape
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    x = torch.randn(B, D1, D2, D3, 32, generator=g)
+    w = torch.randn(27, 32, 32, generator=g) * 0.05
+    bias = torch.randn(32, generator=g) * 0.1
+    xr = x.double().permute(0, 4, 1, 2, 3).requires_grad_(True)                       # NCDHW
+    wr = w.double().reshape(3, 3, 3, 32, 32).permute(4, 3, 0, 1, 2).requires_grad_(True)   # [cout, cin, k1, k2, k3]
+    br = bias.double().requires_grad_(True)
+    yr = F.conv3d(xr, wr, br, padding=pad)
+    dy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+    yr.backward(dy)
+    rel = lambda a, b: (np.linalg.norm(a - b) / np.linalg.norm(b))
+    y = rams.conv3d(x.cuda(), w.cuda(), bias.cuda(), pad=pad)
+    assert rel(y.cpu().numpy(), yr.detach().permute(0, 2, 3, 4, 1).numpy()) < 2e-6
+    dy_dev = dy.permute(0, 2, 3, 4, 1).float().contiguous().cuda()
+    gw, gb = rams.conv3d_wgrad(x.cuda(), dy_dev, pad=pad)
+    want_gw = wr.grad.permute(2, 3, 4, 1, 0).reshape(27, 32, 32).numpy()
+    assert rel(gw.cpu().numpy(), want_gw) < 5e-6 and rel(gb.cpu().numpy(), br.grad.numpy()) < 5e-6
+    gw2, _ = rams.conv3d_wgrad(x.cuda(), dy_dev, pad=pad)
+    assert torch.equal(gw, gw2)                                                        # fixed-order reduction
+    if pad == 1:
+        dx = rams.conv3d_dgrad(dy_dev, w.cuda())
+        assert rel(dx.cpu().numpy(), xr.grad.permute(0, 2, 3, 4, 1).numpy()) < 5e-6
