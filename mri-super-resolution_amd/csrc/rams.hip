@@ -412,44 +412,69 @@ __global__ void __launch_bounds__(256) conv3d_dgrad_weights_kernel(float* __rest
 struct Conv3dWgradParams {
     const float* x;    // [B][D1][D2][D3][32]
     const float* dy;   // [B][O1][O2][O3][32]
-    float* slab;       // [blocks][27][32][32]
+    float* slab;       // [B * blocks_per_b][27][32][32]
     int B, D1, D2, D3, O1, O2, O3, pad;
-    long long nvox, vox_per_block;
+    int vox_per_block;   // output voxels of ONE batch element per block (multiple of 8)
 };
 
+// grid = (blocks_per_b, B): a block stays inside one batch element, so both operands are read through per-block buffer
+// resources with 32-bit offsets, and an out-of-range tap is an offset past the resource (reads 0) -- per tap and voxel
+// one add, one select, one load.  The f32 MFMA shares the VALU lanes: address arithmetic is what this loop must not do.
 __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWgradParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
-    const long long v0 = (long long)blockIdx.x * p.vox_per_block;
-    const long long v1 = min(p.nvox, v0 + p.vox_per_block);
+    const int b = blockIdx.y;
     const int ovox = p.O1 * p.O2 * p.O3;
+    const int v0 = blockIdx.x * p.vox_per_block, v1 = min(ovox, v0 + p.vox_per_block);
+    const long long xb = (long long)p.D1 * p.D2 * p.D3 * RC, yb = (long long)ovox * RC;
+    const __amdgpu_buffer_rsrc_t srdx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + b * xb), 0, (int)(xb * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + b * yb), 0, (int)(yb * 4), 0x00020000);
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int d1[4], d2[4], d3[4];
+    int delta[4], sh[4];   // wave-uniform: byte offset of the tap inside x, bit position of the tap in the 27-bit mask
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int tap = wave + 8 * t;   // tap 27..31: idle slot of waves 3..7
-        d1[t] = tap / 9 - p.pad;
-        d2[t] = (tap / 3) % 3 - p.pad;
-        d3[t] = tap % 3 - p.pad;
+        delta[t] = (((tap / 9) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3) * RC * 4;
+        sh[t] = tap < 27 ? tap : 31;    // bit 31 of the mask is never set
     }
-    for (long long vb = v0; vb < v1; vb += 8) {   // 8 voxels = 4 MFMA k-steps; lane half h takes voxels vb + 2 s + h
+    // this lane's running output voxel: v0 + h, + 2 per MFMA k-step
+    int v = v0 + h;
+    int o3 = v % p.O3, o2 = (v / p.O3) % p.O2, o1 = v / (p.O3 * p.O2);
+    for (int vb = v0; vb < v1; vb += 8) {
         float dyv[4], xv[4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long v = vb + 2 * s + h;
             const bool ok = v < v1;
-            const int b = (int)(v / ovox), o = (int)(v - (long long)b * ovox);
-            const int o3 = o % p.O3, o2 = (o / p.O3) % p.O2, o1 = o / (p.O3 * p.O2);
-            dyv[s] = ok ? p.dy[v * RC + l32] : 0.f;
+            const int base = ((((o1 - p.pad) * p.D2 + (o2 - p.pad)) * p.D3 + (o3 - p.pad)) * RC + l32) * 4;
+            unsigned m1 = 0, m2 = 0, m3 = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int i1 = o1 + d1[t], i2 = o2 + d2[t], i3 = o3 + d3[t];
-                const bool in = ok && wave + 8 * t < 27 && (unsigned)i1 < (unsigned)p.D1 && (unsigned)i2 < (unsigned)p.D2 &&
-                                (unsigned)i3 < (unsigned)p.D3;
-                xv[t][s] = in ? p.x[((((long long)b * p.D1 + i1) * p.D2 + i2) * p.D3 + i3) * RC + l32] : 0.f;
+            for (int d = 0; d < 3; ++d) {
+                m1 |= ((unsigned)(o1 + d - p.pad) < (unsigned)p.D1) ? (1u << d) : 0u;
+                m2 |= ((unsigned)(o2 + d - p.pad) < (unsigned)p.D2) ? (1u << d) : 0u;
+                m3 |= ((unsigned)(o3 + d - p.pad) < (unsigned)p.D3) ? (1u << d) : 0u;
+            }
+            unsigned mk = 0;
+#pragma unroll
+            for (int e1 = 0; e1 < 3; ++e1)
+#pragma unroll
+                for (int e2 = 0; e2 < 3; ++e2) mk |= (((m1 >> e1) & (m2 >> e2) & 1u) ? m3 : 0u) << (9 * e1 + 3 * e2);
+            if (!ok) mk = 0;
+            dyv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdy, ok ? (v * RC + l32) * 4 : 0x7F000000, 0, 0));
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                xv[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         srdx, ((mk >> sh[t]) & 1u) ? base + delta[t] : 0x7F000000, 0, 0));
+            v += 2;
+            o3 += 2;
+            while (o3 >= p.O3) {
+                o3 -= p.O3;
+                if (++o2 >= p.O2) {
+                    o2 = 0;
+                    ++o1;
+                }
             }
         }
 #pragma unroll
@@ -458,25 +483,27 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][s], dyv[s], acc[t], 0, 0, 0);
     }
     // C/D map: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 h (ci)
+    const long long blk = (long long)b * gridDim.x + blockIdx.x;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int tap = wave + 8 * t;
         if (tap < 27) {
-            float* dst = p.slab + ((long long)blockIdx.x * 27 + tap) * RC * RC + l32;
+            float* dst = p.slab + (blk * 27 + tap) * RC * RC + l32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * h) * RC] = acc[t][r];
         }
     }
 }
 
-constexpr int WGRAD_BLOCKS = 512;
+constexpr int WGRAD_BLOCKS = 512;        // target number of blocks (two per CU)
+constexpr int WGRAD_BLOCKS_MAX = 1024;   // slabs the workspace is sized for (blocks_per_b * B never exceeds max(512, B))
 int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
 int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st);
 int64_t colsum_ws_floats(int64_t n, int C, int G);
 int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab, hipStream_t st);
 
 size_t rams_conv3d_wgrad_ws_floats(long long nvox) {
-    const size_t a = (size_t)WGRAD_BLOCKS * CONV_W_FLOATS + (size_t)reduce_tmp_floats(WGRAD_BLOCKS, CONV_W_FLOATS);
+    const size_t a = (size_t)WGRAD_BLOCKS_MAX * CONV_W_FLOATS + (size_t)reduce_tmp_floats(WGRAD_BLOCKS_MAX, CONV_W_FLOATS);
     const size_t b = (size_t)colsum_ws_floats(nvox, RC, 1);
     return (a > b ? a : b) + 64;
 }
@@ -507,15 +534,21 @@ int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int
     p.x = x; p.dy = dy; p.slab = ws;
     p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3; p.pad = pad;
     p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
-    p.nvox = (long long)B * p.O1 * p.O2 * p.O3;
-    p.vox_per_block = ((p.nvox + WGRAD_BLOCKS - 1) / WGRAD_BLOCKS + 7) / 8 * 8;
+    const int ovox = p.O1 * p.O2 * p.O3;
+    int blocks_per_b = WGRAD_BLOCKS / B;
+    if (blocks_per_b < 1) blocks_per_b = 1;
+    p.vox_per_block = ((ovox + blocks_per_b - 1) / blocks_per_b + 7) / 8 * 8;
+    blocks_per_b = (ovox + p.vox_per_block - 1) / p.vox_per_block;
+    const int nslabs = blocks_per_b * B;
+    INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 31) && nslabs <= WGRAD_BLOCKS_MAX, INR_E_INVALID,
+                "conv3d wgrad: one batch element must stay below 2 GiB and B below %d", WGRAD_BLOCKS_MAX);
     {
         ProfScope ps(KC_OTHER, st);
-        hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(WGRAD_BLOCKS), dim3(512), 0, st, p);
+        hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(blocks_per_b, B), dim3(512), 0, st, p);
         INR_LAUNCH_CHECK();
     }
-    if (int rc = launch_reduce_slabs(gw, ws, WGRAD_BLOCKS, CONV_W_FLOATS, ws + (size_t)WGRAD_BLOCKS * CONV_W_FLOATS, st)) return rc;
-    if (gb) return launch_colsum(gb, dy, nullptr, p.nvox, RC, 1, ws, st);
+    if (int rc = launch_reduce_slabs(gw, ws, nslabs, CONV_W_FLOATS, ws + (size_t)nslabs * CONV_W_FLOATS, st)) return rc;
+    if (gb) return launch_colsum(gb, dy, nullptr, (long long)B * ovox, RC, 1, ws, st);
     return 0;
 }
 
