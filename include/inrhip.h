@@ -78,6 +78,10 @@ typedef struct inr_rams_desc {
  * Every tensor starts at a multiple of 4 floats (16 B): offsets come from inr_siren_param_offsets. */
 
 int         inr_version(void);
+/* 0 for the product build.  Non-zero = a diagnostic build (bit 0: in-kernel time stamps -DINR_STAMPS, bit 1: ablated
+ * kernels -DH3_ABLATE, bit 2: padded LDS -DH3_EXTRA_LDS): its timings and, with bit 1, its RESULTS are not the product's.
+ * The Python binding refuses such a library unless it was selected explicitly (INR_LIB=...). */
+int         inr_build_flags(void);
 const char* inr_last_error(void);
 int         inr_device_caps(int device, inr_device_caps_t* out);
 

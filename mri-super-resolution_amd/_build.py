@@ -2,26 +2,55 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
 travels to the GPU box with the repo snapshot (it is git-ignored, not gpurun-ignored).
+Translation units are compiled in parallel into ``csrc/_obj/*.o`` (only the stale ones) and linked.
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libinrhip.so")
-SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "siren_small.hip", "hybrid_fit.hip")
+SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "rams_train.hip", "siren_small.hip",
+           "hybrid_fit.hip")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+
+
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))] + \
+        [os.path.join(INCLUDE, "inrhip.h")]
+
+
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "inrhip.h")]
+    deps = [os.path.join(CSRC, f) for f in _sources()] + _headers()
     return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build_diagnostic(defines=("-DINR_STAMPS",), out=None, verbose=False) -> str:
+    """A diagnostic build (time stamps, ablations) into its OWN file -- never over the product library.  Select it with
+    ``INR_LIB=<path>``; ``inr_build_flags()`` of such a library is non-zero and the binding refuses it otherwise."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    out = out or os.path.join(PKG_DIR, "libinrhip_diag.so")
+    cmd = [hipcc] + FLAGS + list(defines) + ["-shared", "-I", INCLUDE, "-I", CSRC, "-o", out] + \
+        [os.path.join(CSRC, s) for s in _sources()]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return out
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -31,15 +60,35 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libinrhip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, "-I", CSRC, "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+    os.makedirs(OBJ, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    jobs = []
+    for src in _sources():
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
+            jobs.append([hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", path, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+        for res in pool.map(run, jobs):
+            if res.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    res = run(link)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    if "--diag" in sys.argv:
+        print(build_diagnostic(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DINR_STAMPS",), verbose=True))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True))

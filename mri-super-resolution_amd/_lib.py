@@ -42,6 +42,7 @@ class DeviceCaps(C.Structure):
 # name -> (restype, argtypes); must list EVERY symbol declared in include/inrhip.h
 SIGNATURES = {
     "inr_version": (C.c_int, []),
+    "inr_build_flags": (C.c_int, []),
     "inr_last_error": (C.c_char_p, []),
     "inr_device_caps": (C.c_int, [C.c_int, C.POINTER(DeviceCaps)]),
     "inr_mgrid": (C.c_int, [c_f32p, c_i64p, C.c_int, C.c_int64, C.c_int64, c_stream]),
@@ -123,17 +124,23 @@ def lib():
     """The loaded library with argtypes set.  Raises InrHipUnavailable when it is not built."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("INR_LIB") or LIB_PATH       # INR_LIB: an explicitly selected (diagnostic) build
+        if not os.path.exists(path):
             raise InrHipUnavailable(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no fallback path.")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
         if handle.inr_version() != 1:
             raise InrHipUnavailable(f"libinrhip.so ABI version {handle.inr_version()} != 1: rebuild")
+        if handle.inr_build_flags() != 0 and not os.environ.get("INR_LIB"):
+            raise InrHipUnavailable(
+                f"{path} is a DIAGNOSTIC build (inr_build_flags() = {handle.inr_build_flags()}: time stamps / ablated "
+                "kernels); rebuild the product library (`python mri-super-resolution_amd/_build.py --force`) or select the "
+                "diagnostic one explicitly with INR_LIB=<path>")
         _LIB = handle
     return _LIB
 

@@ -69,6 +69,27 @@ int h3_tensor_amax(unsigned* out, const float* x, long long n, hipStream_t strea
 int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, _Float16* planes,
                     unsigned* amax, unsigned* zero_slots, int n_zero, hipStream_t stream);
 int param_grad_splits(int64_t n, int in_f, int out_f);
+// pre-split (HL32) path: gemm_hp.inc
+bool hp_head_ok(int hidden);
+int gemm_build_flags();
+int hp_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* amax,
+                    unsigned* wnorm, hipStream_t stream);
+int hp_convert(char* out, const float* x, long long rows, int cols, HpScale sc, hipStream_t stream);
+int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc, hipStream_t stream);
+int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
+                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream);
+int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
+                  float* colsum_slab, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so, hipStream_t stream);
+int hp_param_grad_splits(int64_t n, int in_f, int out_f);
+int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
+                        HpScale sa, HpScale sb, hipStream_t stream);
+int hp_head_bound(float* out, const float* W, const float* bias, int hidden, const unsigned* tmax, const unsigned* wtmax,
+                  float inv_count, float omega, hipStream_t stream);
+int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
+                    float clamp_min, hipStream_t stream);
+int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
+                 const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
+                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream);
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
                           int out_f, hipStream_t stream, const H3Args* h3 = nullptr);
 int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, hipStream_t st);
@@ -134,8 +155,10 @@ extern int g_mfma16;
 extern int g_h3;
 extern int g_h3_wide;
 static int g_h3_serpentine = 1;
+static int g_hp = 1;   // pre-split (HL32) GEMM path inside the fused entry points; inr_debug_set(7, 0) falls back to gemm_h3
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
+extern int g_stamp_class, g_stamp_nth;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
 static const int64_t MAX_ROWS = (1ll << 31) - 256;
@@ -176,7 +199,8 @@ static Layout make_layout(const inr_siren_desc_t* d) {
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
 
 static size_t param_grad_ws_floats(int64_t n, int in_f, int out_f) {
-    const int splits = param_grad_splits(n, in_f, out_f);
+    const int s1 = param_grad_splits(n, in_f, out_f), s2 = hp_param_grad_splits(n, in_f, out_f);
+    const int splits = s1 > s2 ? s1 : s2;
     const size_t len = (size_t)in_f * out_f;
     const size_t slabs = (size_t)splits * len + (size_t)reduce_tmp_floats(splits, (int64_t)len);
     return max2(slabs, (size_t)colsum_ws_floats(n, out_f, 1));
@@ -285,6 +309,38 @@ static H3Args h3_param_grad_args(const H3Ctx& c, int l) {
     return a;
 }
 
+
+// ---- pre-split (HL32) context: gemm_hp.inc ------------------------------------------------------------------------------
+// Shares the H3Ctx region: 256 bytes of slots, then 8 bytes per weight (HL32 [out][in], then HL32 [in][out] per layer).
+// slots: [l] max|W_l| bits, [8 + l] measured max|dz_l| bits, [16 + l] wnorm_l (float bits) -- all three zeroed every step;
+// [24] max|x| (floor 1), [25] max|target|, [26] max|weight| (per call); [27] bound of the head's dz (float, every step)
+static bool hp_eligible(const inr_siren_desc_t* d, const Layout& L) {
+    if (!g_hp || !g_h3 || g_force_generic || !h3_eligible(L)) return false;
+    return d->out_features == 1 && hp_head_ok(d->hidden_features);
+}
+struct HpNet {
+    const H3Ctx* c;
+    const Layout* L;
+    char* w_hl(int l) const { return reinterpret_cast<char*>(c->planes) + 2 * c->plane_off[l]; }
+    char* wT_hl(int l) const { return w_hl(l) + 4ll * L->fan_in[l] * L->fan_out[l]; }
+    HpScale w_scale(int l) const { HpScale s; s.meas = c->slots + l; s.mul = 1.f; return s; }
+    HpScale x_scale() const { HpScale s; s.meas = c->slots + 24; s.mul = 1.f; return s; }
+    HpScale act_scale(int l) const { return l == 0 ? x_scale() : HpScale{}; }   // input of sine layer l
+    float* head_bound() const { return reinterpret_cast<float*>(c->slots + 27); }
+};
+static int hp_refresh_weights(const HpNet& net, const float* params, hipStream_t st) {
+    const Layout& L = *net.L;
+    const float* W[8];
+    int of[8], inf[8];
+    for (int l = 0; l < L.n_sine; ++l) {
+        W[l] = params + L.w_off[l];
+        of[l] = L.fan_out[l];
+        inf[l] = L.fan_in[l];
+    }
+    INR_HIP(hipMemsetAsync(net.c->slots, 0, sizeof(unsigned) * 24, st));
+    return hp_weight_split(W, of, inf, L.n_sine, reinterpret_cast<char*>(net.c->planes), net.c->slots, net.c->slots + 16, st);
+}
+
 static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
     const int64_t blocks = head_fused_blocks(n);
     const size_t fused = (size_t)(2 * blocks * hidden + reduce_tmp_floats(blocks, hidden) + 2 * blocks);   // + loss / sum-g partials
@@ -335,6 +391,7 @@ using namespace inr;
 extern "C" {
 
 int inr_version(void) { return INR_ABI_VERSION; }
+int inr_build_flags(void) { return gemm_build_flags(); }
 const char* inr_last_error(void) { return g_err; }
 
 int inr_device_caps(int device, inr_device_caps_t* out) {
@@ -496,16 +553,31 @@ int inr_siren_param_offsets(const inr_siren_desc_t* desc, int64_t* offsets) {
 size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
     if (check_desc(desc)) return 0;
     return 2 * round_up((size_t)(n > 0 ? n : 1) * desc->hidden_features * sizeof(float), 256) +
-           h3_ctx_bytes(make_layout(desc));
+           h3_ctx_bytes(make_layout(desc)) + round_up((size_t)(n > 0 ? n : 1) * desc->in_features * sizeof(float), 256);
 }
 
 static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const float* params, const float* x,
                               int64_t n, float* y, int use_clamp, float clamp_min, float* buf0, float* buf1,
-                              hipStream_t st, const H3Ctx* h3 = nullptr) {
+                              hipStream_t st, const H3Ctx* h3 = nullptr, char* xhl = nullptr) {
     const float* cur = x;
     float* bufs[2] = {buf0, buf1};
     if (h3 && h3->on) {
         if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
+    }
+    if (h3 && h3->on && xhl) {   // pre-split path: every activation lives in HBM as HL32 (gemm_hp.inc)
+        const HpNet net{h3, &L};
+        if (int rc = hp_convert(xhl, x, n, L.fan_in[0], net.x_scale(), st)) return rc;
+        const char* in = xhl;
+        for (int l = 0; l < L.n_sine; ++l) {
+            char* dst = reinterpret_cast<char*>(bufs[l & 1]);
+            const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+            if (int rc = hp_sine_forward(dst, nullptr, in, net.w_hl(l), params + L.b_off[l], n, L.fan_in[l], L.fan_out[l],
+                                         omega, net.act_scale(l), net.w_scale(l), 0, st))
+                return rc;
+            in = dst;
+        }
+        return hp_head_forward(y, in, params + L.w_off[L.n_sine], params + L.b_off[L.n_sine], n, d->hidden_features,
+                               use_clamp, clamp_min, st);
     }
     for (int l = 0; l < L.n_sine; ++l) {
         float* dst = bufs[l & 1];
@@ -535,18 +607,24 @@ int inr_siren_forward(const inr_siren_desc_t* desc, const float* params, const f
     float* b0 = (float*)workspace;
     float* b1 = (float*)((char*)workspace + half);
     H3Ctx h3;
+    char* xhl = nullptr;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, (char*)workspace + 2 * half);
-        if (int rc = h3_refresh_weights(h3, L, params, (hipStream_t)stream)) return rc;
+        if (hp_eligible(desc, L)) {
+            xhl = (char*)workspace + 2 * half + h3_ctx_bytes(L);
+            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, params, (hipStream_t)stream)) return rc;
+        } else if (int rc = h3_refresh_weights(h3, L, params, (hipStream_t)stream)) {
+            return rc;
+        }
     }
-    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream, &h3);
+    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream, &h3, xhl);
 }
 
 size_t inr_siren_reconstruct_workspace_bytes(const inr_siren_desc_t* desc, int64_t chunk_rows) {
     if (check_desc(desc) || chunk_rows < 1) return 0;
     const size_t feats = round_up((size_t)chunk_rows * desc->in_features * sizeof(float), 256);
     const size_t act = round_up((size_t)chunk_rows * desc->hidden_features * sizeof(float), 256);
-    return feats + 2 * act + h3_ctx_bytes(make_layout(desc));
+    return 2 * feats + 2 * act + h3_ctx_bytes(make_layout(desc));   // second feature buffer: its HL32 image
 }
 
 int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, const int64_t* shape, int dim,
@@ -579,9 +657,15 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
     float* b1 = (float*)((char*)workspace + feats_b + act_b);
     hipStream_t st = (hipStream_t)stream;
     H3Ctx h3;
+    char* xhl = nullptr;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, (char*)workspace + feats_b + 2 * act_b);
-        if (int rc = h3_refresh_weights(h3, L, params, st)) return rc;
+        if (hp_eligible(desc, L)) {
+            xhl = (char*)workspace + feats_b + 2 * act_b + h3_ctx_bytes(L);
+            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, params, st)) return rc;
+        } else if (int rc = h3_refresh_weights(h3, L, params, st)) {
+            return rc;
+        }
     }
     for (int64_t r0 = 0; r0 < total; r0 += chunk_rows) {
         const int64_t rows = (total - r0 < chunk_rows) ? (total - r0) : chunk_rows;
@@ -589,7 +673,7 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
                    : launch_mgrid(feats, shape, dim, r0, rows, st);
         if (rc) return rc;
         rc = siren_forward_impl(desc, L, params, feats, rows, y + r0 * desc->out_features, use_clamp, clamp_min, b0,
-                                b1, st, &h3);
+                                b1, st, &h3, xhl);
         if (rc) return rc;
     }
     return 0;
@@ -597,7 +681,7 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
 
 // workspace carve for the fit: acts (n_sine x n x H), dacts (n_sine x n x H), y, gy, scratch
 struct FitCarve {
-    size_t act_b, out_b, scratch_b, total, h3_off;
+    size_t act_b, out_b, scratch_b, total, h3_off, xhl_off;
 };
 static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n) {
     FitCarve c;
@@ -612,7 +696,8 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     if (mse > scratch) scratch = mse;
     c.scratch_b = round_up(scratch * sizeof(float), 256);
     c.h3_off = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
-    c.total = c.h3_off + h3_ctx_bytes(L);
+    c.xhl_off = c.h3_off + h3_ctx_bytes(L);
+    c.total = c.xhl_off + round_up((size_t)n * d->in_features * sizeof(float), 256);   // HL32 image of the network input
     if (small_path_ok(d, n)) {   // the fused small-network step carves the same workspace differently
         const size_t small = round_up(small_workspace_floats(d, n, L.total) * sizeof(float), 256);
         if (small > c.total) c.total = small;
@@ -688,6 +773,92 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
     return 0;
 }
 
+
+// the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
+// dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound)
+static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
+                                   std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* scratch,
+                                   const float* target, const float* weight, int64_t n, int64_t count_total, float* loss_dst,
+                                   hipStream_t st, const H3Ctx& ctx) {
+    const int H = d->hidden_features, head = L.n_sine;
+    const HpNet net{&ctx, &L};
+    if (int rc = hp_refresh_weights(net, params, st)) return rc;
+    const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
+    const float omega_last = (head - 1 == 0) ? d->first_omega : d->hidden_omega;
+    if (int rc = hp_head_bound(net.head_bound(), params + L.w_off[head], params + L.b_off[head], H, ctx.slots + 25,
+                               weight ? ctx.slots + 26 : nullptr, inv, omega_last, st))
+        return rc;
+    auto act_hl = [&](int l) -> const char* { return l == 0 ? xhl : reinterpret_cast<const char*>(act[l]); };
+    for (int l = 0; l < L.n_sine; ++l) {
+        const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        if (int rc = hp_sine_forward(reinterpret_cast<char*>(act[l + 1]), dact[l], act_hl(l), net.w_hl(l), params + L.b_off[l], n,
+                                     L.fan_in[l], L.fan_out[l], omega, net.act_scale(l), net.w_scale(l), 0, st))
+            return rc;
+    }
+    // scale of dz_l: the head's bound for the last sine layer, else measured max|dz_{l+1}| * wnorm_{l+1} * omega_l
+    auto dz_scale = [&](int l) {
+        HpScale s;
+        if (l == head - 1) {
+            s.wn = net.head_bound();
+            s.mul = 1.f;
+        } else {
+            s.meas = ctx.slots + 8 + l + 1;
+            s.wn = reinterpret_cast<const float*>(ctx.slots + 16 + l + 1);
+            s.mul = fabsf(l == 0 ? d->first_omega : d->hidden_omega) * 1.001f;
+        }
+        return s;
+    };
+    {
+        const int64_t blocks = head_fused_blocks(n);
+        float* slab_b = scratch;
+        float* slab_w = scratch + blocks * H;
+        float* tmp = scratch + 2 * blocks * H;
+        float* part_loss = tmp + reduce_tmp_floats(blocks, H);
+        float* part_g = part_loss + blocks;
+        if (int rc = hp_head_step(reinterpret_cast<char*>(dact[head - 1]), slab_b, slab_w, part_loss, part_g, act_hl(head),
+                                  dact[head - 1], params + L.w_off[head], params + L.b_off[head], target, weight, n, H,
+                                  count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st))
+            return rc;
+        if (int rc = launch_reduce_slabs(grads + L.b_off[head - 1], slab_b, (int)blocks, H, tmp, st)) return rc;
+        if (int rc = launch_reduce_slabs(grads + L.w_off[head], slab_w, (int)blocks, H, tmp, st)) return rc;
+        if (int rc = launch_finish_sum(loss_dst, part_loss, (int)blocks, inv, st)) return rc;
+        if (int rc = launch_finish_sum(grads + L.b_off[head], part_g, (int)blocks, 1.0f, st)) return rc;
+    }
+    for (int l = L.n_sine - 1; l >= 0; --l) {
+        const char* dz = reinterpret_cast<const char*>(dact[l]);
+        const int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);
+        const int64_t len = (int64_t)L.fan_in[l] * L.fan_out[l];
+        if (int rc = hp_param_grad_slabs(scratch, splits, dz, act_hl(l), n, L.fan_in[l], L.fan_out[l], dz_scale(l),
+                                         net.act_scale(l), st))
+            return rc;
+        if (int rc = launch_reduce_slabs(grads + L.w_off[l], scratch, splits, len, scratch + (int64_t)splits * len, st)) return rc;
+        if (l > 0) {
+            const int rows = input_grad_colsum_rows(n);
+            if (int rc = hp_input_grad(reinterpret_cast<char*>(dact[l - 1]), dz, net.wT_hl(l), dact[l - 1], n, L.fan_in[l],
+                                       L.fan_out[l], scratch, ctx.slots + 8 + l - 1, dz_scale(l), net.w_scale(l),
+                                       dz_scale(l - 1), st))
+                return rc;
+            if (int rc = launch_reduce_slabs(grads + L.b_off[l - 1], scratch, rows, L.fan_in[l],
+                                             scratch + (int64_t)rows * L.fan_in[l], st))
+                return rc;
+        }
+    }
+    return 0;
+}
+
+// per call: scales of the network input and of the targets, HL32 image of x
+static int hp_prepare_call(const H3Ctx& ctx, const Layout& L, char* xhl, const float* x, const float* target,
+                           const float* weight, int64_t n, int out_f, hipStream_t st) {
+    if (int rc = h3_tensor_amax(ctx.slots + 25, target, (long long)n * out_f, st, 0u)) return rc;
+    if (weight) {
+        if (int rc = h3_tensor_amax(ctx.slots + 26, weight, (long long)n * out_f, st, 0u)) return rc;
+    }
+    HpScale sx;
+    sx.meas = ctx.slots + 24;
+    sx.mul = 1.f;
+    return hp_convert(xhl, x, n, L.fan_in[0], sx, st);
+}
+
 size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
     if (check_desc(desc) || n < 1) return 0;
     const Layout L = make_layout(desc);
@@ -739,10 +910,20 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
         h3 = h3_make_ctx(L, base + c.h3_off);
         if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
+    const bool hp = hp_eligible(desc, L);
+    char* xhl = base + c.xhl_off;
+    if (hp && n_steps > 0) {
+        if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, st)) return rc;
+    }
     for (int it = 0; it < n_steps; ++it) {
-        if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
-                                          losses ? (losses + it) : loss_sink, st, &h3))
+        if (hp) {
+            if (int rc = fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, 0,
+                                                 losses ? (losses + it) : loss_sink, st, h3))
+                return rc;
+        } else if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
+                                                 losses ? (losses + it) : loss_sink, st, &h3)) {
             return rc;
+        }
         if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
     }
     return 0;
@@ -777,6 +958,12 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, base + c.h3_off);
         if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream, 0x3f800000u)) return rc;
+    }
+    if (hp_eligible(desc, L)) {
+        char* xhl = base + c.xhl_off;
+        if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, (hipStream_t)stream)) return rc;
+        return fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, count_total, loss,
+                                       (hipStream_t)stream, h3);
     }
     return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
                                 (hipStream_t)stream, &h3);
@@ -986,6 +1173,9 @@ int inr_debug_set(int key, int value) {
     if (key == 3) { g_h3 = value; return 0; }
     if (key == 5) { g_h3_serpentine = value; return 0; }
     if (key == 6) { g_h3_wide = value; return 0; }
+    if (key == 7) { g_hp = value; return 0; }
+    if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...
+    if (key == 9) { g_stamp_nth = value; return 0; }     // ... and only the n-th one since this call (counts down)
     if (key == 2) { set_hybrid_variant(value); return 0; }
     return INR_E_INVALID;
 }

@@ -55,6 +55,14 @@ struct H3Args {
     int reverse_m = 0;                  // serpentine row-tile order between consecutive kernels (Infinity Cache reuse)
 };
 
+// power-of-two scale of an HL32 tensor (gemm_hp.inc) from an a-priori bound: bound = [*meas as float bits] * [*wn] * mul
+// (missing factors = 1).  The producer scales by it, every consumer undoes it -- all by evaluating the same expression.
+struct HpScale {
+    const unsigned* meas = nullptr;   // float bits (an atomic-max slot of a FINISHED kernel), nullable
+    const float* wn = nullptr;        // device float, nullable
+    float mul = 0.f;                  // 0 = no scale at all (tensor in [-1, 1]: sine outputs)
+};
+
 enum KernelClass { KC_GEMM_FWD = 0, KC_GEMM_DX = 1, KC_GEMM_DW = 2, KC_OTHER = 3, KC_COUNT = 4 };
 bool prof_enabled();
 void prof_begin(int kernel_class, hipStream_t s);

@@ -811,8 +811,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const Gemm
 }
 
 #include "gemm_h3.inc"
+#include "gemm_hp.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
+int g_stamp_class = -1, g_stamp_nth = 0; // hp kernels: which launch receives g_stamps (class, countdown)
+int gemm_build_flags() {
+    int f = 0;
+#ifdef INR_STAMPS
+    f |= 1;
+#endif
+    if (H3_ABLATE != 0) f |= 2;
+    if (H3_EXTRA_LDS != 0) f |= 4;
+    return f;
+}
+static unsigned long long* hp_stamp_target(int kernel_class) {
+    if (!g_stamps || kernel_class != g_stamp_class) return nullptr;
+    return g_stamp_nth-- == 0 ? g_stamps : nullptr;
+}
 int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
 int g_mfma16 = 1;         // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
 int g_h3 = 1;             // split-fp16 GEMMs: 0 off, 1 on where the caller supplies scales/planes (fused fit), 2 also in
@@ -1065,6 +1080,198 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
     const bool vec = vec_ok(dz, x, out_f, in_f, out_f, in_f);
     ProfScope ps(KC_GEMM_DW, stream);
     return launch_gemm<false, false, EPI_PLAIN>(p, vec, stream);
+}
+
+
+// =====================================================================================================
+// host side of the pre-split path (gemm_hp.inc)
+// =====================================================================================================
+bool hp_head_ok(int hidden) { return hidden == 128 || hidden == 256 || hidden == 512 || hidden == 1024; }
+
+int hp_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* amax,
+                    unsigned* wnorm, hipStream_t stream) {
+    INR_REQUIRE(layers >= 1 && layers <= 8, INR_E_INVALID, "hp_weight_split: %d layers", layers);
+    WeightSplitJobs aj{};
+    HpWeightJobs jobs{};
+    char* cur = planes;
+    int max_tiles = 1, max_ci = 1;
+    for (int l = 0; l < layers; ++l) {
+        const long long n = (long long)out_f[l] * in_f[l];
+        aj.job[l] = WeightSplitJob{W[l], nullptr, nullptr, nullptr, nullptr, amax + l, out_f[l], in_f[l]};
+        jobs.job[l] = HpWeightJob{W[l], cur, cur + 4 * n, amax + l, wnorm + l, out_f[l], in_f[l]};
+        cur += 8 * n;
+        const int t = ((out_f[l] + 63) / 64) * ((in_f[l] + 63) / 64);
+        if (t > max_tiles) max_tiles = t;
+        if ((in_f[l] + 63) / 64 > max_ci) max_ci = (in_f[l] + 63) / 64;
+    }
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(weight_amax_kernel, dim3(32, layers), dim3(256), 0, stream, aj);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hp_wnorm_kernel, dim3(max_ci, layers), dim3(256), 0, stream, jobs);
+    INR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(hp_weight_split_kernel, dim3(max_tiles, layers), dim3(256), 0, stream, jobs);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int hp_convert(char* out, const float* x, long long rows, int cols, HpScale sc, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    const long long n8 = rows * (cols / 8);
+    long long blocks = (n8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(hp_convert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, x, rows, cols, sc);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc, hipStream_t stream) {
+    if (rows <= 0) return 0;
+    long long blocks = (rows * cols + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(hp_unconvert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, out, x, rows, cols, sc);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+static int hp_check_grid(const HpParams& p) {
+    const long long total = (long long)p.tiles_m * p.tiles_n * p.splits;
+    INR_REQUIRE(total > 0 && total < (1ll << 31), INR_E_INVALID, "hp gemm grid out of range (%lld blocks)", total);
+    return 0;
+}
+
+// act (HL32 [n][out_f]) = sin(omega (x W^T + b)); dact (fp32, nullable) = omega cos(.)
+int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
+                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream) {
+    HpParams p{};
+    p.A = x_hl; p.B = W_hl;
+    p.M = (int)n; p.N = out_f; p.K = in_f;
+    p.pitchA = (long long)in_f * 4; p.pitchB = (long long)in_f * 4;
+    p.a_rows = n; p.b_rows = out_f;
+    p.sa = sa; p.sb = sb;
+    p.C_hl = act_hl; p.C2 = dact; p.bias = bias; p.omega = omega;
+    p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (out_f + HP_BN - 1) / HP_BN; p.splits = 1;
+    p.k_per_split = in_f; p.reverse_m = reverse_m;
+    if (int rc = hp_check_grid(p)) return rc;
+    const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n)), block(HP_NTH);
+    p.stamps = hp_stamp_target(KC_GEMM_FWD);
+    ProfScope ps(KC_GEMM_FWD, stream);
+    if (dact) hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// dz_prev (HL32 * 2^ko, written over the bytes of `mul`) = (dz W) * mul; colsum slab [2 ceil(n/128)][in_f]; max|dz_prev|
+int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
+                  float* colsum_slab, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so, hipStream_t stream) {
+    HpParams p{};
+    p.A = dz_hl; p.B = WT_hl;
+    p.M = (int)n; p.N = in_f; p.K = out_f;
+    p.pitchA = (long long)out_f * 4; p.pitchB = (long long)out_f * 4;
+    p.a_rows = n; p.b_rows = in_f;
+    p.sa = sa; p.sb = sb; p.so = so;
+    p.C_hl = dzprev_hl; p.mul = mul; p.colsum = colsum_slab; p.amax_out = amax_out;
+    p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (in_f + HP_BN - 1) / HP_BN; p.splits = 1;
+    p.k_per_split = out_f;
+    if (int rc = hp_check_grid(p)) return rc;
+    const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n)), block(HP_NTH);
+    p.stamps = hp_stamp_target(KC_GEMM_DX);
+    ProfScope ps(KC_GEMM_DX, stream);
+    hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int hp_param_grad_splits(int64_t n, int in_f, int out_f) {
+    const long long tiles = (long long)((out_f + HP_BM - 1) / HP_BM) * ((in_f + HP_BN - 1) / HP_BN);
+    const long long ksteps = (n + HP_BK - 1) / HP_BK;
+    long long want = (256 + tiles - 1) / tiles;          // one 512-thread block per CU
+    const long long max_by_work = (ksteps + 15) / 16;    // at least 16 K-tiles per split
+    long long s = want < max_by_work ? want : max_by_work;
+    const long long min_by_offset = (n * (long long)(in_f > out_f ? in_f : out_f) * 4 + (1ll << 30) - 1) >> 30;   // 32-bit offsets
+    if (s < min_by_offset) s = min_by_offset;
+    // fp32 accumulation over one split's rows is a plain running sum: beyond ~16k rows its rounding error (relative to a
+    // gradient that is a small mean of large terms) shows at the 1e-5 tier (256^3 volume: 8.8e-5 with 131,072 rows per
+    // split) -- keep the register accumulation short and let the fixed-order slab reduction do the rest
+    const long long min_by_len = (n + 16383) / 16384;
+    if (s < min_by_len) s = min_by_len;
+    if (s < 1) s = 1;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+
+// slabs[splits][out_f][in_f] = partial dz^T x over row ranges (dz, x: HL32)
+int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
+                        HpScale sa, HpScale sb, hipStream_t stream) {
+    HpParams p{};
+    p.A = dz_hl; p.B = x_hl;
+    p.M = out_f; p.N = in_f; p.K = (int)n;
+    p.pitchA = (long long)out_f * 4; p.pitchB = (long long)in_f * 4;
+    p.a_rows = n; p.b_rows = n;
+    p.sa = sa; p.sb = sb;
+    p.C2 = slabs;
+    p.tiles_m = (out_f + HP_BM - 1) / HP_BM; p.tiles_n = (in_f + HP_BN - 1) / HP_BN; p.splits = splits;
+    const long long ksteps = (n + HP_BK - 1) / HP_BK;
+    p.k_per_split = (int)((ksteps + splits - 1) / splits) * HP_BK;
+    p.slab_stride = (long long)out_f * in_f;
+    INR_REQUIRE((long long)p.k_per_split * (p.pitchA > p.pitchB ? p.pitchA : p.pitchB) < (1ll << 31), INR_E_INVALID,
+                "hp_param_grad_slabs: row range per split too large for 32-bit offsets");
+    if (int rc = hp_check_grid(p)) return rc;
+    const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n * p.splits)), block(HP_NTH);
+    p.stamps = hp_stamp_target(KC_GEMM_DW);
+    ProfScope ps(KC_GEMM_DW, stream);
+    hipLaunchKernelGGL((gemm_hp_kernel<HP_RC, HPE_SLAB>), grid, block, 0, stream, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int hp_head_bound(float* out, const float* W, const float* bias, int hidden, const unsigned* tmax, const unsigned* wtmax,
+                  float inv_count, float omega, hipStream_t stream) {
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(hp_head_bound_kernel, dim3(1), dim3(256), 0, stream, out, W, bias, hidden, tmax, wtmax, inv_count, omega);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
+                    float clamp_min, hipStream_t stream) {
+    long long blocks = (n + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    const dim3 grid((unsigned)blocks), block(256);
+    ProfScope ps(KC_OTHER, stream);
+    switch (hidden) {
+        case 128: hipLaunchKernelGGL(hp_head_forward_kernel<2>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
+        case 256: hipLaunchKernelGGL(hp_head_forward_kernel<4>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
+        case 512: hipLaunchKernelGGL(hp_head_forward_kernel<8>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
+        case 1024: hipLaunchKernelGGL(hp_head_forward_kernel<16>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
+        default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_forward: hidden = %d", hidden);
+    }
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// slab_b / slab_w: [blocks][hidden], part_loss / part_g: [blocks], blocks = ceil(n / 256)
+int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
+                 const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
+                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream) {
+    const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
+    const int rpb = 256;
+    const dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
+    ProfScope ps(KC_OTHER, stream);
+#define HP_HEAD_STEP(CPL)                                                                                                   \
+    hipLaunchKernelGGL(hp_head_step_kernel<CPL>, grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss, part_g, a_hl, dact, \
+                       W, bias, t, wgt, n, inv, amax_out, so, rpb)
+    switch (hidden) {
+        case 128: HP_HEAD_STEP(2); break;
+        case 256: HP_HEAD_STEP(4); break;
+        case 512: HP_HEAD_STEP(8); break;
+        case 1024: HP_HEAD_STEP(16); break;
+        default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_step: hidden = %d", hidden);
+    }
+#undef HP_HEAD_STEP
+    INR_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace inr

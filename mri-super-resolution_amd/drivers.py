@@ -67,6 +67,15 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
     if seed is not None:
         torch.manual_seed(seed)
     B = torch.from_numpy(fourier_matrix(vol.ndim, mapping_size, ff_scale, seed)).cuda()
+    if group is not None and torch.distributed.get_world_size(group) > 1:
+        # one fit, several ranks: everybody uses the first rank's Fourier matrix (the weights follow in the fitter)
+        src = torch.distributed.get_global_rank(group, 0)
+        if torch.distributed.get_backend(group) == "nccl":
+            torch.distributed.broadcast(B, src=src, group=group)
+        else:
+            Bh = B.cpu()
+            torch.distributed.broadcast(Bh, src=src, group=group)
+            B.copy_(Bh)
     model = Siren(2 * mapping_size, hidden_features, hidden_layers, 1).cuda()
     data = ImageFitting_set([lr_vol])
     model_input = input_mapping(data.coords[0], B)                        # built once per fit (superresDWI.py:122)

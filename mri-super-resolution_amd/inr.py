@@ -352,19 +352,31 @@ class SirenFitter:
 class ShardedSirenFitter(SirenFitter):
     """One fit whose coordinate rows are split over the ranks of a process group (SURVEY.md 8 e): every rank holds
     identical weights and its own row shard; per step the local forward/backward (``inr_siren_loss_grad``, mean taken
-    over the GLOBAL row count) is followed by ONE all-reduce(sum) of the flat gradient (+ the loss) -- 3.68 MB for
-    Siren(256,512,3,1) over RCCL/xGMI -- and an identical local Adam step.  Mathematically the full-batch step of
-    superresDWI.py:134-138; the summation order differs from the single-GPU run (tier T3/T4 parity, not bitwise)."""
+    over the GLOBAL row count) is followed by ONE all-reduce(sum) of the flat gradient with the loss riding in a spare
+    slot behind it -- 3.68 MB for Siren(256,512,3,1) over RCCL/xGMI -- and an identical local Adam step.  Mathematically
+    the full-batch step of superresDWI.py:134-138; the summation order differs from the single-GPU run (tier T3/T4 parity,
+    not bitwise).  At construction the weights and the Adam state of the group's first rank are broadcast, so ranks
+    that drew different initialisations (unseeded RNG) still fit ONE network."""
 
     def __init__(self, model: Siren, global_rows: int, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, group=None):
         super().__init__(model, lr=lr, betas=betas, eps=eps)
         self.global_rows = int(global_rows)
         self.group = group
-        self._loss = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+        # gradient buffer with the loss slot behind it: one collective per step
+        self._gbuf = torch.zeros(self.total + 4, dtype=torch.float32, device=self.flat.device)
+        self.grads = self._gbuf[:self.total]
+        self._loss = self._gbuf[self.total:self.total + 1]
+        self.sync_replicas()
+
+    def _world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
 
     def _all_reduce(self, t):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if self._world() == 1:
             return
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -372,6 +384,25 @@ class ShardedSirenFitter(SirenFitter):
             h = t.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             t.copy_(h)
+
+    def _broadcast(self, t):
+        import torch.distributed as dist
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        if dist.get_backend(self.group) == "nccl":
+            dist.broadcast(t, src=src, group=self.group)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+
+    def sync_replicas(self):
+        """Every rank takes the weights, Adam moments and step count of the group's first rank."""
+        if self._world() == 1:
+            return
+        count = torch.tensor([float(self.step_count)], dtype=torch.float64, device=self.flat.device)
+        for t in (self.flat, self.m, self.v, count):
+            self._broadcast(t)
+        self.step_count = int(count.item())
 
     def step(self, model_input, target, n_steps=1, weight=None):
         self._check_views()
@@ -383,12 +414,11 @@ class ShardedSirenFitter(SirenFitter):
         for it in range(int(n_steps)):
             self._workspace = ops.siren_loss_grad(self.desc, self.flat, self.grads, x, t, w, count_total, self._loss,
                                                   self._workspace)
-            self._all_reduce(self.grads)
-            self._all_reduce(self._loss)
+            self._all_reduce(self._gbuf)          # gradient + loss in one message
             self.step_count += 1
             ops.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
                           self.eps)
-            losses[it] = self._loss[0]
+            losses[it:it + 1].copy_(self._loss)   # device-side, no host sync
         return losses[:n_steps]
 
 

@@ -10,8 +10,10 @@ side), REFLECT padding without edge repeat, WeightNormalization kernel = g * v /
 kernel axis except the output-channel one, depth_to_space in DCR order, tf.round = half-to-even -- are taken
 from the libraries' documented behaviour and are pinned only by this repo's own tests.
 
-Parameters live in a flat dict of numpy arrays keyed ``<layer>/v`` ([k1,k2(,k3),Cin,Cout] TF kernel layout),
-``<layer>/g`` ([Cout]) and ``<layer>/b`` ([Cout]); ``rams_layer_names`` lists the layers in graph order.
+Parameters live in a flat dict of numpy arrays (or torch tensors, for autograd) keyed ``<layer>/v`` ([k1,k2(,k3),Cin,Cout]
+TF kernel layout), ``<layer>/g`` ([Cout]) and ``<layer>/b`` ([Cout]).  The layer list is NOT a table: ``rams_layer_specs``
+runs the graph once with a recording parameter store, so it is derived from this file's forward pass alone and is
+independent of the product's ``rams.rams_layer_specs`` (tests compare the two).
 """
 from __future__ import annotations
 
@@ -23,27 +25,114 @@ MEAN = 7433.6436   # network.py:18
 STD = 2353.0723    # network.py:19
 
 
+class _Recorder(dict):
+    """Parameter store that records (name, kernel shape, cin, cout) of every convolution the forward pass BUILDS, in
+    build order -- the way the Keras functional graph of network.py:110-155 comes into being.  Missing entries are
+    created on first use (zeros), so one dry forward on a tiny input yields the layer list without any table."""
+
+    def __init__(self):
+        super().__init__()
+        self.order = []
+
+    def declare(self, name, ks, cin, cout):
+        if f"{name}/v" not in self:
+            self.order.append((name, tuple(ks), int(cin), int(cout)))
+            self[f"{name}/v"] = np.zeros(tuple(ks) + (cin, cout), np.float32)
+            self[f"{name}/g"] = np.ones(cout, np.float32)
+            self[f"{name}/b"] = np.zeros(cout, np.float32)
+
+
+def _kernel(params, name, dtype):
+    """tfa WeightNormalization: kernel = g * v / ||v||, norm over all axes but the last (network.py:29-35)."""
+    v, g = params[f"{name}/v"], params[f"{name}/g"]
+    if not torch.is_tensor(v):
+        v, g = torch.from_numpy(np.asarray(v)), torch.from_numpy(np.asarray(g))
+    v, g = v.to(torch.float64), g.to(torch.float64)
+    norm = torch.sqrt((v ** 2).sum(dim=tuple(range(v.dim() - 1)), keepdim=True))
+    w = g * v / norm
+    # the forward pass of the fp32 pipeline uses the fp32-rounded folded kernel; autograd (float64 runs) sees the fold
+    return w.to(dtype)
+
+
+def effective_kernel(params, name):
+    return _kernel(params, name, torch.float32).detach().numpy()
+
+
+def _conv(x, params, name, cout, ks, padding):
+    """x: [B, D1, D2(, D3), C] channels-last; TF kernel [k..., Cin, Cout]; `cout` / `ks` as the reference declares the
+    layer (conv3d_weightnorm(filters, kernel_size, ...), network.py:29-35)."""
+    dims = len(ks)
+    if isinstance(params, _Recorder):
+        params.declare(name, ks, x.shape[-1], cout)
+    w = _kernel(params, name, x.dtype)
+    b = params[f"{name}/b"]
+    b = (b if torch.is_tensor(b) else torch.from_numpy(np.asarray(b))).to(x.dtype)
+    if dims == 3:
+        xt = x.permute(0, 4, 1, 2, 3)
+        wt = w.permute(4, 3, 0, 1, 2)
+        pad = tuple(k // 2 for k in ks) if padding == "same" else 0
+        return F.conv3d(xt, wt, b, padding=pad).permute(0, 2, 3, 4, 1)
+    xt = x.permute(0, 3, 1, 2)
+    wt = w.permute(3, 2, 0, 1)
+    pad = tuple(k // 2 for k in ks) if padding == "same" else 0
+    return F.conv2d(xt, wt, b, padding=pad).permute(0, 2, 3, 1)
+
+
+def _reflect_hw(x):
+    """tf.pad(..., [[0,0],[1,1],[1,1],...], mode='REFLECT') on axes 1 and 2 (network.py:37-39, :145)."""
+    idx = lambda n: torch.tensor([1] + list(range(n)) + [n - 2])
+    return x.index_select(1, idx(x.shape[1])).index_select(2, idx(x.shape[2]))
+
+
+def _attention_block(x, params, prefix, filters, ks, r):
+    """RFAB (3-D kernel, network.py:42-63) / RTAB (2-D kernel, network.py:65-87)."""
+    dims = len(ks)
+    one = (1,) * dims
+    res = x
+    y = torch.relu(_conv(x, params, f"{prefix}/conv1", filters, ks, "same"))
+    y = _conv(y, params, f"{prefix}/conv2", filters, ks, "same")
+    pooled = y.mean(dim=tuple(range(1, 1 + dims)), keepdim=True)
+    s = torch.relu(_conv(pooled, params, f"{prefix}/squeeze", int(filters / r), one, "same"))
+    s = torch.sigmoid(_conv(s, params, f"{prefix}/excite", filters, one, "same"))
+    return y * s + res
+
+
+def depth_to_space(x, bs):
+    """tf.nn.depth_to_space, NHWC, DCR: out[b, h*bs+i, w*bs+j, c] = in[b, h, w, (i*bs + j)*C + c]."""
+    b, h, w, c = x.shape
+    co = c // (bs * bs)
+    return x.reshape(b, h, w, bs, bs, co).permute(0, 1, 3, 2, 4, 5).reshape(b, h * bs, w * bs, co)
+
+
+def rams_graph(params, x, scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
+    """network.py:110-155 on a torch tensor x [B, H, W, channels] (any float dtype; differentiable)."""
+    k3, k2 = (kernel_size,) * 3, (kernel_size,) * 2
+    xn = (x - MEAN) / STD                                                          # normalize, :21-23
+    g_res = xn
+    y = _reflect_hw(xn.unsqueeze(-1))                                              # :117-119
+    y = _conv(y, params, "stem", filters, k3, "same")                              # low-level features, :121
+    trunk_res = y
+    for i in range(N):                                                             # residual feature attention blocks
+        y = _attention_block(y, params, f"rfab{i}", filters, k3, r)
+    y = _conv(y, params, "trunk", filters, k3, "same") + trunk_res                 # :128-129
+    for i in range(int(np.floor_divide(channels, 3))):                             # temporal reduction, :132-137
+        y = _reflect_hw(y)
+        y = _attention_block(y, params, f"red{i}/rfab", filters, k3, r)
+        y = torch.relu(_conv(y, params, f"red{i}/conv", filters, (3, 3, 3), "valid"))
+    y = _conv(y, params, "up", scale ** 2, (3, 3, 3), "valid")[..., 0, :]            # upscaling, :139-141
+    y = depth_to_space(y, 3)                                                       # the reference hard-codes 3, :141
+    g = _reflect_hw(g_res)                                                         # global path, :144-148
+    g = _attention_block(g, params, "rtab", 9, k2, r)                              # RTAB(x, 9, ...), :146
+    g = depth_to_space(_conv(g, params, "global", scale ** 2, (3, 3), "valid"), 3)
+    return (y + g) * STD + MEAN                                                    # denormalize, :25-27
+
+
 def rams_layer_specs(scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
-    """[(name, kernel_shape_without_channels, cin, cout)] in the order the reference builds them (network.py:119-147)."""
-    k3 = (kernel_size,) * 3
-    k2 = (kernel_size,) * 2
-    specs = [("stem", k3, 1, filters)]
-
-    def rfab(prefix):
-        return [(f"{prefix}/conv1", k3, filters, filters), (f"{prefix}/conv2", k3, filters, filters),
-                (f"{prefix}/squeeze", (1, 1, 1), filters, int(filters / r)),
-                (f"{prefix}/excite", (1, 1, 1), int(filters / r), filters)]
-
-    for i in range(N):
-        specs += rfab(f"rfab{i}")
-    specs.append(("trunk", k3, filters, filters))
-    for i in range(channels // 3):
-        specs += rfab(f"red{i}/rfab")
-        specs.append((f"red{i}/conv", (3, 3, 3), filters, filters))
-    specs.append(("up", (3, 3, 3), filters, scale ** 2))
-    specs += [("rtab/conv1", k2, 9, 9), ("rtab/conv2", k2, 9, 9), ("rtab/squeeze", (1, 1), 9, int(9 / r)),
-              ("rtab/excite", (1, 1), int(9 / r), 9), ("global", (3, 3), 9, scale ** 2)]
-    return specs
+    """[(name, kernel shape, cin, cout)] discovered by one dry run of ``rams_graph`` on an 8 x 8 input (no table)."""
+    rec = _Recorder()
+    with torch.no_grad():
+        rams_graph(rec, torch.zeros(1, 8, 8, channels), scale, filters, kernel_size, channels, r, N)
+    return rec.order
 
 
 def init_rams_params(seed=0, perturb_g=True, **kw):
@@ -63,74 +152,11 @@ def init_rams_params(seed=0, perturb_g=True, **kw):
     return params
 
 
-def effective_kernel(params, name):
-    """tfa WeightNormalization: kernel = g * v / ||v||, norm over all axes but the last (network.py:29-35)."""
-    v = params[f"{name}/v"].astype(np.float64)
-    norm = np.sqrt((v ** 2).sum(axis=tuple(range(v.ndim - 1)), keepdims=True))
-    return (params[f"{name}/g"].astype(np.float64) * v / norm).astype(np.float32)
-
-
-def _conv(x, params, name, padding, dims):
-    """x: [B, D1, D2(, D3), C] channels-last; TF kernel [k..., Cin, Cout]."""
-    w = torch.from_numpy(effective_kernel(params, name))
-    b = torch.from_numpy(params[f"{name}/b"])
-    if dims == 3:
-        xt = x.permute(0, 4, 1, 2, 3)
-        wt = w.permute(4, 3, 0, 1, 2)
-        pad = tuple(k // 2 for k in w.shape[:3]) if padding == "same" else 0
-        return F.conv3d(xt, wt, b, padding=pad).permute(0, 2, 3, 4, 1)
-    xt = x.permute(0, 3, 1, 2)
-    wt = w.permute(3, 2, 0, 1)
-    pad = tuple(k // 2 for k in w.shape[:2]) if padding == "same" else 0
-    return F.conv2d(xt, wt, b, padding=pad).permute(0, 2, 3, 1)
-
-
-def _reflect_hw(x):
-    """tf.pad(..., [[0,0],[1,1],[1,1],...], mode='REFLECT') on axes 1 and 2 (network.py:37-39, :145)."""
-    idx = lambda n: torch.tensor([1] + list(range(n)) + [n - 2])
-    return x.index_select(1, idx(x.shape[1])).index_select(2, idx(x.shape[2]))
-
-
-def _attention_block(x, params, prefix, dims):
-    """RFAB (dims=3, network.py:42-63) / RTAB (dims=2, network.py:65-87)."""
-    res = x
-    y = torch.relu(_conv(x, params, f"{prefix}/conv1", "same", dims))
-    y = _conv(y, params, f"{prefix}/conv2", "same", dims)
-    pooled = y.mean(dim=tuple(range(1, 1 + dims)), keepdim=True)
-    s = torch.relu(_conv(pooled, params, f"{prefix}/squeeze", "same", dims))
-    s = torch.sigmoid(_conv(s, params, f"{prefix}/excite", "same", dims))
-    return y * s + res
-
-
-def depth_to_space(x, bs):
-    """tf.nn.depth_to_space, NHWC, DCR: out[b, h*bs+i, w*bs+j, c] = in[b, h, w, (i*bs + j)*C + c]."""
-    b, h, w, c = x.shape
-    co = c // (bs * bs)
-    return x.reshape(b, h, w, bs, bs, co).permute(0, 1, 3, 2, 4, 5).reshape(b, h * bs, w * bs, co)
-
-
-def rams_forward(params, x, scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
-    """network.py:110-155.  x: float32 array/tensor [B, H, W, channels] -> [B, scale*H, scale*W, 1]."""
+def rams_forward(params, x, **kw):
+    """network.py:110-155.  x: float32 array/tensor [B, H, W, channels] -> numpy [B, scale*H, scale*W, 1]."""
     x = torch.as_tensor(np.asarray(x, np.float32)) if not torch.is_tensor(x) else x.float()
     with torch.no_grad():
-        xn = (x - MEAN) / STD
-        g_res = xn
-        y = _reflect_hw(xn.unsqueeze(-1))
-        y = _conv(y, params, "stem", "same", 3)
-        trunk_res = y
-        for i in range(N):
-            y = _attention_block(y, params, f"rfab{i}", 3)
-        y = _conv(y, params, "trunk", "same", 3) + trunk_res
-        for i in range(channels // 3):
-            y = _reflect_hw(y)
-            y = _attention_block(y, params, f"red{i}/rfab", 3)
-            y = torch.relu(_conv(y, params, f"red{i}/conv", "valid", 3))
-        y = _conv(y, params, "up", "valid", 3)[..., 0, :]
-        y = depth_to_space(y, scale)
-        g = _reflect_hw(g_res)
-        g = _attention_block(g, params, "rtab", 2)
-        g = depth_to_space(_conv(g, params, "global", "valid", 2), scale)
-        return ((y + g) * STD + MEAN).numpy()
+        return rams_graph(params, x, **kw).numpy()
 
 
 def predict_tensor(params, x, **kw):

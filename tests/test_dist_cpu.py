@@ -1,13 +1,9 @@
 """CPU tests of the multi-GPU driver logic: deterministic LPT partitioning and the fixed-size metric gather,
 exercised with world_size = 2 on the gloo backend (the GPU runs use the same code over nccl/RCCL)."""
-import os
-import socket
-
 import pytest
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from mri_super_resolution_amd import dist as inr_dist
+from tests.mp_util import run_ranks
 
 
 def test_lpt_partition_properties():
@@ -60,42 +56,30 @@ def test_gather_single_process():
     assert out == [{"id": 3.0, "psnr": 32.5}]
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        costs = [5.0, 3.0, 9.0, 1.0, 7.0]
-        plan = inr_dist.partition_fits(costs, world)
-        recs = inr_dist.gather_records({"rank": float(rank), "load": sum(costs[i] for i in plan[rank])})
-        local = [{"job": float(i), "cost": costs[i], "rank": float(rank)} for i in plan[rank]]
-        jobs = inr_dist.gather_job_records(local, ["job", "cost", "rank"], max_jobs_per_rank=4)
-        q.put((rank, plan, recs, jobs))
-    finally:
-        dist.destroy_process_group()
+def _worker(rank, world):
+    costs = [5.0, 3.0, 9.0, 1.0, 7.0]
+    plan = inr_dist.partition_fits(costs, world)
+    recs = inr_dist.gather_records({"rank": float(rank), "load": sum(costs[i] for i in plan[rank])})
+    local = [{"job": float(i), "cost": costs[i], "rank": float(rank)} for i in plan[rank]]
+    jobs = inr_dist.gather_job_records(local, ["job", "cost", "rank"], max_jobs_per_rank=4)
+    return plan, recs, jobs
 
 
 def test_gather_world_size_2_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get() for _ in procs]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
-    results.sort()
-    (r0, plan0, recs0, jobs0), (r1, plan1, recs1, jobs1) = results
+    (plan0, recs0, jobs0), (plan1, recs1, jobs1) = run_ranks(_worker, 2, timeout=120)
     assert plan0 == plan1 == [[2, 1, 3], [4, 0]]                    # same schedule on every rank, no communication
     assert recs0 == recs1 == [{"load": 13.0, "rank": 0.0}, {"load": 12.0, "rank": 1.0}]
     assert jobs0 == jobs1
     assert sorted(j["job"] for j in jobs0) == [0.0, 1.0, 2.0, 3.0, 4.0]
     assert {j["job"]: j["rank"] for j in jobs0} == {2.0: 0.0, 1.0: 0.0, 3.0: 0.0, 4.0: 1.0, 0.0: 1.0}
+
+
+def _failing_worker(rank, world):
+    if rank == 1:
+        raise RuntimeError("rank 1 dies before its first collective")
+    return inr_dist.gather_records({"rank": float(rank)})
+
+
+def test_harness_reports_a_dead_rank_instead_of_hanging():
+    with pytest.raises(AssertionError, match="rank 1 dies"):
+        run_ranks(_failing_worker, 2, timeout=60)

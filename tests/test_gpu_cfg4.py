@@ -1,0 +1,82 @@
+"""-m gpu: BASELINE config 4 -- all 11 anon_data/patNN_mean_b0 volumes (z = 24 / 28 / 34) through the HIP path.
+
+Inputs are committed fixtures (tests/golden/patients_mean_b0.npz + pat07_volume.npz, written by oracle/gen_golden*.py);
+the expected values of the z = 24 / z = 34 cases come from the REAL reference loop run in the build container
+(tests/golden/cfg4_ref_steps.npz: superresDWI.py:105-138 protocol on SRDWI.Siren, 6 Adam steps)."""
+import numpy as np
+import pytest
+import torch
+
+from mri_super_resolution_amd import dist as inr_dist
+from mri_super_resolution_amd import drivers
+from oracle import inr_oracle as O
+from tests.mp_util import run_ranks
+
+pytestmark = pytest.mark.gpu
+PATIENTS = ("07", "08", "09", "30", "37", "41", "45", "47", "76", "78", "82")
+
+
+def _volumes(golden):
+    rest = golden("patients_mean_b0.npz")
+    return [golden("pat07_volume.npz")["vol"] if p == "07" else rest[f"pat{p}"] for p in PATIENTS]
+
+
+@pytest.mark.parametrize("pt,z", [("41", 24), ("76", 34)])
+def test_short_fit_tracks_the_reference(golden, pt, z):
+    """z = 24 and z = 34 volumes: 6 steps of the 3-D fit against the reference's own losses / reconstruction (T3)."""
+    vol = golden("patients_mean_b0.npz")[f"pat{pt}"]
+    assert vol.shape == (128, 128, z)
+    ref = golden("cfg4_ref_steps.npz")
+    res = drivers.fit_volume(vol, steps=6, seed=0, chunk_steps=6)
+    assert res["n_coords"] == 64 * 64 * z and tuple(res["recon"].shape) == (256, 256, z)
+    assert res["final_loss"] == pytest.approx(float(ref[f"pat{pt}/losses"][-1]), rel=1e-3)
+    got = drivers.reconstruct(res["model"], (128, 128, z), res["B"]).cpu().numpy()
+    assert O.rel_l2(got.reshape(-1)[::13], ref[f"pat{pt}/recon_strided13"]) < 1e-4
+    assert np.linalg.norm(got.astype(np.float64)) == pytest.approx(float(ref[f"pat{pt}/recon_norm"]), rel=1e-4)
+
+
+def test_all_eleven_patients_one_gpu(golden):
+    """The patient loop (superresDWI.py:29) over the 11 real volumes on one GPU: short fits, complete records."""
+    vols = _volumes(golden)
+    assert sorted(v.shape[2] for v in vols) == [24] * 3 + [28] * 5 + [34] * 3
+    recs = drivers.run_volumes(vols, steps=40, seed=0, chunk_steps=20)
+    assert [int(r["job"]) for r in recs] == list(range(11))
+    for r, v in zip(recs, vols):
+        assert int(r["n_coords"]) == 64 * 64 * v.shape[2]
+        assert np.isfinite(r["final_loss"]) and r["final_loss"] < 0.05
+        assert 15.0 < r["psnr_db"] < 45.0 and 0.0 < r["ssim_mean"] <= 1.0
+        assert r["t_fit"] > 0 and r["t_recon"] > 0
+
+
+def _two_rank_worker(rank, world, steps):
+    from tests.conftest import GOLDEN
+    import os
+    rest = np.load(os.path.join(GOLDEN, "patients_mean_b0.npz"))
+    vols = [np.load(os.path.join(GOLDEN, "pat07_volume.npz"))["vol"] if p == "07" else rest[f"pat{p}"] for p in PATIENTS]
+    return drivers.run_volumes(vols, steps=steps, seed=0, chunk_steps=steps)
+
+
+def test_eleven_patients_two_ranks_with_a_gang(golden):
+    """2 ranks (gloo, both on the test GPU) on the real 11-volume list: the plan row-shards one 34-slice volume over both
+    ranks (a gang) and packs the other ten whole; every rank ends with the same 11 records."""
+    vols = _volumes(golden)
+    costs = [float(64 * 64 * v.shape[2]) * 8 for v in vols]
+    plan = inr_dist.plan_fits(costs, 2)
+    assert len(plan["gangs"]) == 1 and plan["gangs"][0][1] == [0, 1] and vols[plan["gangs"][0][0]].shape[2] == 34
+    assert sorted([plan["gangs"][0][0]] + [j for w in plan["whole"] for j in w]) == list(range(11))
+    recs0, recs1 = run_ranks(_two_rank_worker, 2, (8,), timeout=600)
+    assert recs0 == recs1 and [int(r["job"]) for r in recs0] == list(range(11))
+    single = drivers.fit_volume(vols[plan["gangs"][0][0]], steps=8, seed=0, chunk_steps=8, return_recon=False)
+    ganged = recs0[plan["gangs"][0][0]]
+    assert ganged["final_loss"] == pytest.approx(single["final_loss"], rel=2e-3)
+    assert all(np.isfinite(r["final_loss"]) for r in recs0)
+
+
+def test_full_length_fit_quality_t4(golden):
+    """Tier T4: the full 2,500-step config-1 fit (pat07 slice 11, x2) is judged on PSNR over seeds 0-3, against the
+    reference's own numbers (32.59 / 32.29 / 32.37 / 32.21 dB, mean 32.365, sigma 0.16; reference
+    vs itself at another thread count: +-0.12 dB).  Mean within 0.15 dB, every seed inside the 31.9 - 32.8 band."""
+    hr = golden("pat07_slice11.npz")["hr"]
+    vals = [drivers.fit_volume(hr, steps=2500, seed=s, return_recon=False)["psnr_db"] for s in range(4)]
+    assert abs(float(np.mean(vals)) - 32.365) < 0.15, vals
+    assert all(31.9 < v < 32.8 for v in vals), vals

@@ -13,9 +13,30 @@ from oracle import rams_port as R
 pytestmark = pytest.mark.gpu
 
 
-def test_layer_specs_agree_with_oracle():
-    assert rams.rams_layer_specs() == R.rams_layer_specs()
+def test_layer_table_matches_the_graph_the_oracle_builds():
+    """The product's layer table against the list the oracle DISCOVERS by running its own restatement of
+    network.py:110-155 with a recording parameter store (two derivations: a table here, a graph walk there)."""
+    for cfg in (dict(), dict(N=2), dict(filters=16, r=4, N=1)):
+        assert rams.rams_layer_specs(**cfg) == R.rams_layer_specs(**cfg)
     assert len(rams.rams_layer_specs()) == 71
+
+
+def test_full_size_stack_matches_oracle():
+    """BASELINE config 3 shape: (1, 128, 128, 9) and a batch of 2 at 128 x 128 -- the multi-tile paths, tile edges and
+    per-image offsets the toy sizes never reach (~265 GFLOP per image on the host oracle)."""
+    params = R.init_rams_params(seed=4, perturb_g=True)
+    model = rams.RAMS(3, 32, 3, 9, 8, 12, params=params)
+    x = (np.random.default_rng(11).random((2, 128, 128, 9)) * 30000 + 1000).astype(np.float32)
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    want = R.rams_forward(params, x)
+    got = model(x).cpu().numpy()
+    assert got.shape == (2, 384, 384, 1)
+    assert O.rel_l2((got - R.MEAN) / R.STD, (want - R.MEAN) / R.STD) < 5e-5
+    single = model(x[:1]).cpu().numpy()
+    assert np.array_equal(single, got[:1])                      # batch 1 (the reference's call shape) == slice of batch 2
+    pt = rams.predict_tensor(model, x[:1]).cpu().numpy()
+    ref = R.predict_tensor(params, x[:1])
+    assert (pt != ref).mean() < 1e-2 and np.abs(pt - ref).max() <= 1.0
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 24, 20), (3, 16, 16)])

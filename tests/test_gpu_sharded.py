@@ -1,17 +1,13 @@
 """-m gpu: one fit split over ranks (SURVEY 8 e): shard gradients add up to the full-batch gradient, and a 2-process
 run (gloo all-reduce, both ranks on the one test GPU) follows the single-process trajectory."""
-import os
-import socket
-
 import numpy as np
 import pytest
 import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 import mri_super_resolution_amd as inr
 from mri_super_resolution_amd import ops
 from oracle import inr_oracle as O
+from tests.mp_util import run_ranks
 
 pytestmark = pytest.mark.gpu
 
@@ -43,27 +39,15 @@ def test_shard_gradients_add_up():
     assert abs(acc_l.item() - full_l.item()) < 1e-6 * full_l.item()
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        x, t, w = _problem()
-        n = x.shape[0]
-        lo, hi = (0, n // 2 + 37) if rank == 0 else (n // 2 + 37, n)
-        torch.manual_seed(0)
-        net = inr.Siren(64, 128, 2, 1).cuda()
-        fitter = inr.ShardedSirenFitter(net, global_rows=n, lr=1e-4)
-        losses = fitter.step(x[lo:hi].cuda(), t[lo:hi].cuda(), n_steps=6, weight=w[lo:hi].cuda())
-        q.put((rank, losses.cpu().numpy(), fitter.flat.cpu().numpy()))
-    finally:
-        dist.destroy_process_group()
+def _fit_worker(rank, world, seed_per_rank):
+    x, t, w = _problem()
+    n = x.shape[0]
+    lo, hi = (0, n // 2 + 37) if rank == 0 else (n // 2 + 37, n)
+    torch.manual_seed(100 + rank if seed_per_rank else 0)      # different draws per rank: the fitter must broadcast
+    net = inr.Siren(64, 128, 2, 1).cuda()
+    fitter = inr.ShardedSirenFitter(net, global_rows=n, lr=1e-4)
+    losses = fitter.step(x[lo:hi].cuda(), t[lo:hi].cuda(), n_steps=6, weight=w[lo:hi].cuda())
+    return losses.cpu().numpy(), fitter.flat.cpu().numpy()
 
 
 def test_two_rank_fit_matches_single_process():
@@ -73,21 +57,23 @@ def test_two_rank_fit_matches_single_process():
     ref = inr.SirenFitter(net, lr=1e-4)
     ref_losses = ref.step(x.cuda(), t.cuda(), n_steps=6, weight=w.cuda()).cpu().numpy()
     ref_flat = ref.flat.cpu().numpy()
-
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = sorted([q.get() for _ in procs], key=lambda r: r[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    (_, l0, f0), (_, l1, f1) = results
+    (l0, f0), (l1, f1) = run_ranks(_fit_worker, 2, (False,), timeout=240)
     assert np.array_equal(f0, f1)                                # identical replicas after identical Adam steps
     assert np.allclose(l0, l1) and np.allclose(l0, ref_losses, rtol=1e-5)
     assert O.rel_l2(f0, ref_flat) < 1e-5
+
+
+def test_two_rank_fit_with_different_rank_seeds_is_one_network():
+    """Ranks that drew different initial weights still fit ONE network: rank 0's weights are broadcast at construction."""
+    torch.manual_seed(100)
+    net = inr.Siren(64, 128, 2, 1).cuda()
+    x, t, w = _problem()
+    ref = inr.SirenFitter(net, lr=1e-4)
+    ref_losses = ref.step(x.cuda(), t.cuda(), n_steps=6, weight=w.cuda()).cpu().numpy()
+    (l0, f0), (l1, f1) = run_ranks(_fit_worker, 2, (True,), timeout=240)
+    assert np.array_equal(f0, f1)
+    assert np.allclose(l0, l1) and np.allclose(l0, ref_losses, rtol=1e-5)
+    assert O.rel_l2(f0, ref.flat.cpu().numpy()) < 1e-5
 
 
 def _volumes():
@@ -99,17 +85,10 @@ def _volumes():
             for z in (2, 5, 2)]
 
 
-def _run_volumes_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from mri_super_resolution_amd import drivers
-        recs = drivers.run_volumes(_volumes(), steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=0,
-                                   chunk_steps=10)
-        q.put((rank, recs))
-    finally:
-        dist.destroy_process_group()
+def _run_volumes_worker(rank, world, seed):
+    from mri_super_resolution_amd import drivers
+    return drivers.run_volumes(_volumes(), steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=seed,
+                               chunk_steps=10)
 
 
 def test_run_volumes_with_a_row_sharded_fit():
@@ -123,19 +102,18 @@ def test_run_volumes_with_a_row_sharded_fit():
     assert plan["gangs"] == [(1, [0, 1])] and sorted(j for w in plan["whole"] for j in w) == [0, 2]
     want = [drivers.fit_volume(v, steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=0, chunk_steps=10,
                                return_recon=False) for v in vols]
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_run_volumes_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = sorted([q.get() for _ in procs], key=lambda r: r[0])
-    for p in procs:
-        p.join(180)
-        assert p.exitcode == 0
-    recs0, recs1 = results[0][1], results[1][1]
+    recs0, recs1 = run_ranks(_run_volumes_worker, 2, (0,), timeout=300)
     assert recs0 == recs1 and [int(r["job"]) for r in recs0] == [0, 1, 2]
     for rec, ref in zip(recs0, want):
         assert rec["n_coords"] == ref["n_coords"]
         assert rec["final_loss"] == pytest.approx(ref["final_loss"], rel=2e-3)     # sharded: another summation order
         assert rec["psnr_db"] == pytest.approx(ref["psnr_db"], abs=0.05)
+
+
+def test_run_volumes_unseeded_ranks_still_agree():
+    """seed=None: every rank draws its own Fourier matrix and weights; the sharded fit must still be ONE fit (both
+    ranks report the same records, finite, and the sharded job's loss went down)."""
+    recs0, recs1 = run_ranks(_run_volumes_worker, 2, (None,), timeout=300)
+    assert recs0 == recs1 and [int(r["job"]) for r in recs0] == [0, 1, 2]
+    assert all(np.isfinite(r["final_loss"]) and np.isfinite(r["psnr_db"]) for r in recs0)
+    assert recs0[1]["psnr_db"] > 15.0
