@@ -222,6 +222,19 @@ int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int he
                void* stream);
 int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream);
 
+/* ---- (f)-2: per-voxel acquisition combinations (SRDWI.py:143-152 calculate_combinations, mapped over all voxels by a
+ * 32-process pool at superresDWI.py:57-76).  raw_b0 [n_voxels], raw_bk [n_voxels][nk] (k = 1..3) fp32 ->
+ * out [n_voxels][4][K], K = n1*n2*n3, combination index in itertools.product order (the last b-value's index fastest). */
+int inr_acquisition_products(float* out, const float* raw_b0, const float* raw_b1, const float* raw_b2, const float* raw_b3,
+                             int64_t n_voxels, int n1, int n2, int n3, void* stream);
+
+/* ---- (f)-3: the spline baseline every SSIM row is reported against (superresDWI.py:172-191) -----------------------
+ * skimage.transform.rescale(img, s, anti_aliasing=True) with its default order (1) for s >= 1: skimage 0.20 hands this
+ * to scipy.ndimage.zoom(order=1, mode='mirror', grid_mode=True); the anti-aliasing filter has sigma 0 when up-scaling.
+ * in [n_images][H][W] fp32 -> out [n_images][OH][OW] fp32; coordinates and weights in double. */
+int inr_rescale2d_linear(float* out, const float* in, int n_images, int height, int width, int out_height, int out_width,
+                         void* stream);
+
 /* ---- a-13/a-14: RAMS forward + predict_tensor (network.py:91-155, prediction.py:76-83) --------------------------
  * x [B][H][W][channels] fp32 (uint16-range values) -> out [B][scale*H][scale*W] fp32.  clip_round != 0 applies
  * predict_tensor's clip to [0, 2^16] and round-half-to-even.

@@ -6,8 +6,9 @@ The directory name carries a hyphen (it is the project name), so import it throu
 ``sys.path`` to get drop-in ``SRDWI`` / ``INRmodel`` / ``nn_mri`` modules for the reference's drivers.
 
 Layout:  csrc/ (HIP kernels + C ABI, built into libinrhip.so) . _lib.py (ctypes binding) . ops.py
-(tensor wrappers) . inr.py (reference module surface + fused fit / reconstruct) . metrics.py .
-dist.py (fit partitioning over GPUs, metric gather).
+(tensor wrappers) . inr.py (reference module surface + fused fit / reconstruct) . metrics.py . baselines.py (spline
+rescale) . drivers.py (the reference's driver loops) . dist.py (fit partitioning over GPUs, metric gather) . matio.py
+(.mat level 5) . reports.py (CSV schemas) . contrast.py (case / calculate_contrast) . scripts/ (superresDWI, master).
 """
 from ._lib import InrHipError, InrHipUnavailable  # noqa: F401
 from .ops import InrDeviceError  # noqa: F401

@@ -1,10 +1,12 @@
 """Drop-in for the INR-side ``nn_mri`` module (master.py:1, INR_ERD.py:1, automate_INR.py:9): 2-D
 ``get_mgrid(sidelen, dim)``, PIL-style ``ImageFitting_set``, ``Siren``/``SineLayer``/``PN``/
 ``input_mapping``.  ``Siren`` returns ``(output, coords)`` as master.py:142 expects when constructed
-through this module.  The DICOM / contrast helpers of the reference are outside the hot path and are
-not provided."""
+through this module.  master.py:1's whole import line resolves: ``cases`` (the patient list the reference never
+published: empty until a driver fills it), ``case``, ``calculate_contrast`` (host arithmetic as in the
+reference) and ``save_dicom`` (DICOM export is out of scope: the name raises a clear error when called)."""
 import _bootstrap  # noqa: F401
 from mri_super_resolution_amd import inr as _inr  # noqa: E402
+from mri_super_resolution_amd.contrast import calculate_contrast, case, cases, save_dicom  # noqa: F401,E402
 from mri_super_resolution_amd.inr import ImageFitting_set, SineLayer, get_mgrid, input_mapping  # noqa: F401,E402
 
 

@@ -122,12 +122,15 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int
                 double b2, double eps, hipStream_t st);
 int launch_sincos_probe(float* s, float* c, const float* x, int64_t n, hipStream_t st);
 int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st);
+int launch_acquisition_products(float* out, const float* r0, const float* r1, const float* r2, const float* r3, int64_t nvox,
+                                int n1, int n2, int n3, hipStream_t st);
 int metric_workspace_doubles(int nimg);
 int launch_psnr(double* out, const float* x, const float* y, int nimg, int64_t per_image, double data_range,
                 double* ws, hipStream_t st);
 int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, int W, int win, double data_range,
                 int use_mask, float mask_thr, double* ws, hipStream_t st);
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
+int launch_rescale_linear(float* out, const float* in, int nimg, int H, int W, int OH, int OW, hipStream_t st);
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st);
 void set_hybrid_variant(int v);
@@ -159,6 +162,7 @@ static int g_hp = 1;   // pre-split (HL32) GEMM path inside the fused entry poin
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
 extern int g_stamp_class, g_stamp_nth;
+extern int g_hp_persistent, g_hp_stagger;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
 static const int64_t MAX_ROWS = (1ll << 31) - 256;
@@ -453,6 +457,14 @@ int inr_linear_tanh_head_forward(float* y, float* dy, const float* a, const floa
     INR_REQUIRE(y && a && W, INR_E_INVALID, "inr_linear_tanh_head_forward: null pointer");
     INR_REQUIRE(n >= 0 && in_features >= 1 && out_features >= 1, INR_E_INVALID, "inr_linear_tanh_head_forward: bad sizes");
     return launch_head_forward(y, a, W, b, n, in_features, out_features, 2, scale, (hipStream_t)stream, dy);
+}
+
+int inr_acquisition_products(float* out, const float* raw_b0, const float* raw_b1, const float* raw_b2, const float* raw_b3,
+                             int64_t n_voxels, int n1, int n2, int n3, void* stream) {
+    INR_REQUIRE(out && raw_b0 && raw_b1 && raw_b2 && raw_b3, INR_E_INVALID, "inr_acquisition_products: null pointer");
+    INR_REQUIRE(n_voxels >= 0 && n1 >= 1 && n2 >= 1 && n3 >= 1 && (long long)n1 * n2 * n3 < (1 << 24), INR_E_INVALID,
+                "inr_acquisition_products: bad sizes");
+    return launch_acquisition_products(out, raw_b0, raw_b1, raw_b2, raw_b3, n_voxels, n1, n2, n3, (hipStream_t)stream);
 }
 
 int inr_mul(float* out, const float* a, const float* b, int64_t count, void* stream) {
@@ -1089,6 +1101,16 @@ int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pix
     return launch_adc(out, data, bvals, n_pixels, n_b, (hipStream_t)stream);
 }
 
+int inr_rescale2d_linear(float* out, const float* in, int n_images, int height, int width, int out_height, int out_width,
+                         void* stream) {
+    INR_REQUIRE(out && in, INR_E_INVALID, "inr_rescale2d_linear: null pointer");
+    INR_REQUIRE(n_images >= 0 && height >= 1 && width >= 1 && out_height >= 1 && out_width >= 1, INR_E_INVALID,
+                "inr_rescale2d_linear: bad sizes");
+    INR_REQUIRE((long long)height * width < (1ll << 31) && (long long)out_height * out_width < (1ll << 31), INR_E_INVALID,
+                "inr_rescale2d_linear: image too large");
+    return launch_rescale_linear(out, in, n_images, height, width, out_height, out_width, (hipStream_t)stream);
+}
+
 // ---- RAMS ------------------------------------------------------------------------------------------------
 static int check_rams(const inr_rams_desc_t* d) {
     INR_REQUIRE(d != nullptr, INR_E_INVALID, "rams descriptor is null");
@@ -1174,6 +1196,8 @@ int inr_debug_set(int key, int value) {
     if (key == 5) { g_h3_serpentine = value; return 0; }
     if (key == 6) { g_h3_wide = value; return 0; }
     if (key == 7) { g_hp = value; return 0; }
+    if (key == 10) { g_hp_persistent = value; return 0; }
+    if (key == 11) { g_hp_stagger = value; return 0; }
     if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...
     if (key == 9) { g_stamp_nth = value; return 0; }     // ... and only the n-th one since this call (counts down)
     if (key == 2) { set_hybrid_variant(value); return 0; }

@@ -820,7 +820,7 @@ int gemm_build_flags() {
 #ifdef INR_STAMPS
     f |= 1;
 #endif
-    if (H3_ABLATE != 0) f |= 2;
+    if (H3_ABLATE != 0 || HP_ABLATE != 0) f |= 2;
     if (H3_EXTRA_LDS != 0) f |= 4;
     return f;
 }
@@ -1086,6 +1086,18 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
 // =====================================================================================================
 // host side of the pre-split path (gemm_hp.inc)
 // =====================================================================================================
+int g_hp_stagger = 0;      // inr_debug_set(11, n): start phases of the persistent blocks, n * 64 cycles apart (0 = together)
+int g_hp_persistent = 1;   // inr_debug_set(10, 0): one block per tile instead of the persistent walk
+static int hp_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 bool hp_head_ok(int hidden) { return hidden == 128 || hidden == 256 || hidden == 512 || hidden == 1024; }
 
 int hp_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* amax,
@@ -1151,13 +1163,21 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
     p.sa = sa; p.sb = sb;
     p.C_hl = act_hl; p.C2 = dact; p.bias = bias; p.omega = omega;
     p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (out_f + HP_BN - 1) / HP_BN; p.splits = 1;
-    p.k_per_split = in_f; p.reverse_m = reverse_m;
+    p.k_per_split = in_f; p.reverse_m = reverse_m; p.stagger = g_hp_stagger;
     if (int rc = hp_check_grid(p)) return rc;
-    const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n)), block(HP_NTH);
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    const dim3 grid((unsigned)tiles), block(HP_NTH);
     p.stamps = hp_stamp_target(KC_GEMM_FWD);
     ProfScope ps(KC_GEMM_FWD, stream);
-    if (dact) hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
+    if (g_hp_persistent && in_f >= 3 * HP_BK) {
+        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+        if (dact) hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE_STASH>), pgrid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE>), pgrid, block, 0, stream, p);
+    } else if (dact) {
+        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
+    }
     INR_LAUNCH_CHECK();
     return 0;
 }
@@ -1173,12 +1193,18 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
     p.sa = sa; p.sb = sb; p.so = so;
     p.C_hl = dzprev_hl; p.mul = mul; p.colsum = colsum_slab; p.amax_out = amax_out;
     p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (in_f + HP_BN - 1) / HP_BN; p.splits = 1;
-    p.k_per_split = out_f;
+    p.k_per_split = out_f; p.stagger = g_hp_stagger;
     if (int rc = hp_check_grid(p)) return rc;
-    const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n)), block(HP_NTH);
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    const dim3 grid((unsigned)tiles), block(HP_NTH);
     p.stamps = hp_stamp_target(KC_GEMM_DX);
     ProfScope ps(KC_GEMM_DX, stream);
-    hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
+    if (g_hp_persistent && out_f >= 3 * HP_BK) {
+        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+        hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_MUL>), pgrid, block, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
+    }
     INR_LAUNCH_CHECK();
     return 0;
 }

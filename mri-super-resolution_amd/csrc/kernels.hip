@@ -596,6 +596,40 @@ int launch_adam(float* p, const float* g, float* m, float* v, int64_t count, int
     return 0;
 }
 
+// ---- (f)-2: every combination of one acquisition per b-value at every voxel (SRDWI.py:143-152 calculate_combinations,
+// which superresDWI.py:57-76 maps over the voxels with a 32-process pool).  itertools.product order: the LAST b-value's
+// acquisition index runs fastest.  raw_b: [nvox][n_b] fp32 (b = 0: [nvox]); out: [nvox][4][K], K = n1 n2 n3:
+//   out[v][0][c] = raw0[v]; out[v][1][c] = raw1[v][c / (n2 n3)]; out[v][2][c] = raw2[v][(c / n3) % n2]; out[v][3][c] = raw3[v][c % n3]
+__global__ void __launch_bounds__(256) acquisition_products_kernel(float* __restrict__ out, const float* __restrict__ r0,
+                                                                   const float* __restrict__ r1, const float* __restrict__ r2,
+                                                                   const float* __restrict__ r3, int64_t nvox, int n1, int n2,
+                                                                   int n3) {
+    const int K = n1 * n2 * n3;
+    const int64_t total = nvox * 4 * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % K);
+        const int b = (int)((i / K) & 3);
+        const int64_t v = i / (4 * (int64_t)K);
+        float val;
+        if (b == 0) val = r0[v];
+        else if (b == 1) val = r1[v * n1 + c / (n2 * n3)];
+        else if (b == 2) val = r2[v * n2 + (c / n3) % n2];
+        else val = r3[v * n3 + c % n3];
+        out[i] = val;
+    }
+}
+
+int launch_acquisition_products(float* out, const float* r0, const float* r1, const float* r2, const float* r3, int64_t nvox,
+                                int n1, int n2, int n3, hipStream_t st) {
+    const int64_t total = nvox * 4 * n1 * n2 * n3;
+    if (total == 0) return 0;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(acquisition_products_kernel, dim3(blocks_for(total, 256, 1 << 16)), dim3(256), 0, st, out, r0, r1, r2, r3,
+                       nvox, n1, n2, n3);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_mul(float* out, const float* a, const float* b, int64_t count, hipStream_t st) {
     if (count == 0) return 0;
     ProfScope ps(KC_OTHER, st);

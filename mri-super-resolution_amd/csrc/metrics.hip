@@ -285,6 +285,49 @@ int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const
     return 0;
 }
 
+// ---- spline baseline: skimage.transform.rescale(img, s, anti_aliasing=True) for s >= 1 (superresDWI.py:172-191) ---------
+// skimage 0.20 resize -> scipy.ndimage.zoom(img, out/in, order=1, mode='mirror', grid_mode=True) (the anti-aliasing sigma
+// max(0, (1/s - 1)/2) is 0 when up-scaling): out[o] = (1 - f) in[m(i)] + f in[m(i + 1)], x = (o + 0.5) in/out - 0.5,
+// i = floor(x), f = x - i, m = reflection about the edge samples (period 2n - 2).  Coordinates and weights in double.
+__device__ __forceinline__ int mirror_index(int i, int n) {
+    if (n <= 1) return 0;
+    const int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+__global__ void __launch_bounds__(256) rescale_linear_kernel(float* __restrict__ out, const float* __restrict__ in, int nimg, int H,
+                                                             int W, int OH, int OW) {
+    const long long total = (long long)nimg * OH * OW;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int ox = (int)(idx % OW);
+        const int oy = (int)((idx / OW) % OH);
+        const long long b = idx / ((long long)OW * OH);
+        const double y = (oy + 0.5) * ((double)H / OH) - 0.5, x = (ox + 0.5) * ((double)W / OW) - 0.5;
+        const double fy0 = floor(y), fx0 = floor(x);
+        const double wy = y - fy0, wx = x - fx0;
+        const int y0 = mirror_index((int)fy0, H), y1 = mirror_index((int)fy0 + 1, H);
+        const int x0 = mirror_index((int)fx0, W), x1 = mirror_index((int)fx0 + 1, W);
+        const float* img = in + b * H * W;
+        // separable, rows first (axis 0), as scipy applies the 1-D splines
+        const double c0 = (1.0 - wy) * img[(long long)y0 * W + x0] + wy * img[(long long)y1 * W + x0];
+        const double c1 = (1.0 - wy) * img[(long long)y0 * W + x1] + wy * img[(long long)y1 * W + x1];
+        out[idx] = (float)((1.0 - wx) * c0 + wx * c1);
+    }
+}
+
+int launch_rescale_linear(float* out, const float* in, int nimg, int H, int W, int OH, int OW, hipStream_t st) {
+    const long long total = (long long)nimg * OH * OW;
+    if (total == 0) return 0;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(rescale_linear_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, in, nimg, H, W, OH, OW);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st) {
     if (npix == 0) return 0;
     ProfScope ps(KC_OTHER, st);

@@ -22,14 +22,13 @@ import numpy as np
 import torch
 
 from . import dist as inr_dist
-from . import metrics
-from .inr import ImageFitting_set, ShardedSirenFitter, Siren, SirenFitter, input_mapping, reconstruct
+from . import matio, metrics, ops
+from .inr import PN, ImageFitting_set, ShardedSirenFitter, Siren, SirenFitter, input_mapping, reconstruct
 
 
 def load_mat_volume(path: str, key: Optional[str] = None) -> np.ndarray:
     """Reads one array from a MATLAB v5 ``.mat`` (``anon_data/patNN_mean_b0.mat``: key ``data_mean_b0``)."""
-    import scipy.io as sio
-    data = sio.loadmat(path)
+    data = matio.loadmat(path)
     if key is None:
         keys = [k for k, v in data.items() if not k.startswith("__") and isinstance(v, np.ndarray) and v.ndim >= 2]
         if len(keys) != 1:
@@ -132,9 +131,70 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
     return out
 
 
+def acquisition_products(hybrid_raw_norm, te: int = 0) -> np.ndarray:
+    """superresDWI.py:57-76 (``Pool(32).starmap(calculate_combinations, ...)`` over every voxel, each task pickling the
+    whole volume) as ONE device kernel: ``hybrid_raw_norm[b][te]`` (b = 0: [X, Y, Z] or [X, Y, Z, 1]; b = 1..3:
+    [X, Y, Z, n_b]) -> ``acquisitions`` [X, Y, Z, 4, n1*n2*n3] float64 on the host, combination index in
+    itertools.product order (SRDWI.py:143-152)."""
+    dev = ops.require_gpu()
+    raws = [torch.from_numpy(np.ascontiguousarray(hybrid_raw_norm[b][te], dtype=np.float32)).to(dev) for b in range(4)]
+    if raws[0].dim() == 4:
+        raws[0] = raws[0][..., 0].contiguous()
+    return ops.acquisition_products(*raws).cpu().numpy().astype(np.float64)
+
+
+def fit_with_perturbnet(INR: Siren, B: torch.Tensor, mean_dataset: ImageFitting_set, acquisitions: Sequence[np.ndarray],
+                        number_of_epochs: int = 2500, pertubation_epochs: int = 10, PN_dim: int = 128, lr: float = 1e-4,
+                        perturb_lr: float = 1e-6, eps: float = 1 / 128., perturb_net: Optional[PN] = None):
+    """superresDWI.py:108-156: ``number_of_epochs - pertubation_epochs`` full-batch INR steps on the mean image (one fused
+    call), then the alternating tail: odd epochs one more INR step, even epochs one PerturbNet step per acquisition
+    (``loss(INR(input_mapping(PN(x, sample, eps))), acquisition_sample)``, Adam lr 1e-6 on the PerturbNet only).
+    All K acquisition targets are uploaded once and stay on the device (the reference copies one per step, :148).
+
+    With the SRDWI flavour ``Siren.forward`` detaches its input (SRDWI.py:88): no gradient reaches the PerturbNet and
+    ``perturb_optim.step()`` changes nothing -- kept exactly so (the loss is still evaluated).  With
+    ``Siren(flavor='INRmodel')`` (INRmodel.py:147, inrDWI.py) the gradient flows INR input -> Fourier features -> PN.
+    Returns the per-step INR losses (host list) and leaves the trained PerturbNet in ``fit_with_perturbnet.last_pn``."""
+    model_input = input_mapping(mean_dataset.coords[0], B)
+    target = mean_dataset.pixels[0]
+    dataset = ImageFitting_set(list(acquisitions))                                        # K device-resident targets
+    dimension = len(dataset.shape)
+    pn = perturb_net if perturb_net is not None else PN(in_features=model_input.shape[1], hidden_features=PN_dim,
+                                                         dimension=dimension).cuda()
+    fitter = SirenFitter(INR, lr=lr)
+    head = max(number_of_epochs - pertubation_epochs, 0)
+    losses = [fitter.step(model_input, target, head)] if head else []
+    pn_params = [p for p in pn.parameters()]
+    pn_state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in pn_params]
+    pn_steps, pn_losses = 0, []
+    for ctr in range(head, number_of_epochs):
+        if ctr % 2:
+            losses.append(fitter.step(model_input, target, 1))
+            continue
+        for sample in range(len(dataset)):
+            ground_truth = dataset.pixels[sample]
+            perturbed_input = input_mapping(pn(model_input, sample, eps), B)
+            model_output = INR(perturbed_input)
+            loss = ((model_output - ground_truth) ** 2).mean()
+            for p in pn_params:
+                p.grad = None
+            loss.backward()
+            pn_losses.append(loss.detach())
+            if all(p.grad is not None for p in pn_params):                                 # INRmodel flavour only
+                pn_steps += 1
+                for p, (m, v) in zip(pn_params, pn_state):
+                    ops.adam_step(p.data, p.grad.contiguous(), m, v, pn_steps, perturb_lr)
+            for p in INR.parameters():                                                    # inr_optim.zero_grad() of the next
+                p.grad = None                                                             # INR step clears these (:136)
+    fit_with_perturbnet.last_pn = pn
+    fit_with_perturbnet.last_pn_losses = [float(l) for l in pn_losses]
+    return [float(v) for v in torch.cat(losses).cpu()] if losses else []
+
+
 def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Sequence[np.ndarray]] = None,
                        total_steps: int = 3000, seg: int = 150, scale: int = 3, hidden_features: int = 64,
-                       hidden_layers: int = 6, lr: float = 3e-4, seed: Optional[int] = 0) -> Dict[str, object]:
+                       hidden_layers: int = 6, lr: float = 3e-4, seed: Optional[int] = 0,
+                       divide_by: Optional[int] = None) -> Dict[str, object]:
     """master.py:130-160 for one gradient direction: raw 2-D coordinates -> Siren(2, H, L, 1); per epoch one weighted
     Adam step per acquisition (targets are ``2*img-1``, nn_mri.py:174-180); the outputs of the last ``seg`` epochs at
     the native and the x``scale`` grid are averaged.  Returns float64 host arrays like the reference."""
@@ -162,7 +222,9 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
             large += reconstruct(model, (side * scale, side * scale), None, clamp_min=None).double()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    n_snap = min(seg, total_steps)
+    # master.py:162-164 divides by args.seg whatever the number of snapshots taken (step >= total - seg gives seg of them
+    # when total_steps >= seg); `divide_by` reproduces that literally
+    n_snap = divide_by if divide_by is not None else min(seg, total_steps)
     return {"predicted": (predicted / max(n_snap, 1)).cpu().numpy(), "large": (large / max(n_snap, 1)).cpu().numpy(),
             "seconds": dt, "optimizer_steps": total_steps * len(targets),
             "train_voxels_per_s": total_steps * len(targets) * side * side / dt, "model": model}

@@ -85,8 +85,11 @@ class ImageFitting_set(torch.utils.data.Dataset):
         super().__init__()
         first = img_dataset[0]
         pil_like = not isinstance(first, np.ndarray) and hasattr(first, "size") and not hasattr(first, "shape")
-        if pil_like:  # nn_mri flavour: pixel -> 2*pixel-1 (Normalize(0.5,0.5), nn_mri.py:174-180)
+        if pil_like:  # nn_mri flavour: ToTensor then Normalize(0.5, 0.5): pixel -> 2*pixel - 1 (nn_mri.py:174-180)
+            # torchvision's ToTensor divides 8-bit images (PIL mode 'L' -> uint8) by 255 and leaves every other mode as it
+            # is ('F' float32 -- what master.py:122 passes -- and 'I' int32 are only cast)
             arrays = [np.array(im) for im in img_dataset]
+            arrays = [a.astype(np.float32) / 255.0 if a.dtype == np.uint8 else a for a in arrays]
             side = arrays[0].shape[0]
             if any(a.shape != (side, side) for a in arrays):
                 raise ValueError("nn_mri-style ImageFitting_set needs square images of equal size")

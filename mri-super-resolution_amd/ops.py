@@ -175,6 +175,21 @@ def mul(a, b):
     return out
 
 
+def acquisition_products(raw_b0, raw_b1, raw_b2, raw_b3):
+    """All combinations of one acquisition per b-value at every voxel (SRDWI.py:143-152 over superresDWI.py:57-76):
+    raw_b0 [...], raw_bk [..., nk] device fp32 -> [..., 4, n1*n2*n3] in itertools.product order."""
+    for name, t in (("raw_b0", raw_b0), ("raw_b1", raw_b1), ("raw_b2", raw_b2), ("raw_b3", raw_b3)):
+        _chk(t, name)
+    lead = tuple(raw_b0.shape)
+    if any(tuple(t.shape[:-1]) != lead for t in (raw_b1, raw_b2, raw_b3)):
+        raise ValueError("acquisition_products: leading (voxel) shapes differ")
+    n1, n2, n3 = raw_b1.shape[-1], raw_b2.shape[-1], raw_b3.shape[-1]
+    out = torch.empty(lead + (4, n1 * n2 * n3), dtype=torch.float32, device=raw_b0.device)
+    check(lib().inr_acquisition_products(out.data_ptr(), raw_b0.data_ptr(), raw_b1.data_ptr(), raw_b2.data_ptr(),
+                                         raw_b3.data_ptr(), raw_b0.numel(), n1, n2, n3, _stream()), "inr_acquisition_products")
+    return out
+
+
 def linear_head_forward(a, W, b, clamp_min=None):
     _chk(a, "a")
     _chk(W, "weight")

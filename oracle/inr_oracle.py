@@ -265,3 +265,41 @@ def rel_l2(a, b):
     a = np.asarray(a, np.float64).reshape(-1)
     b = np.asarray(b, np.float64).reshape(-1)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---- spline baseline (superresDWI.py:172-191: skimage.transform.rescale(img, s, anti_aliasing=True)) -----------------------
+def rescale_linear(img, scale):
+    """skimage 0.20 ``rescale`` for ``scale >= 1`` on a 2-D float image, restated: ``resize`` with order 1 and mode 'reflect'
+    = ``scipy.ndimage.zoom(img, out/in, order=1, mode='mirror', grid_mode=True)`` after a sigma-0 (identity) anti-aliasing
+    filter.  Pinned against that scipy call in tests/test_baselines_cpu.py (scikit-image itself is absent: unpinned vs skimage).
+    x = (o + 0.5) * in/out - 0.5; i = floor(x); out = (1 - f) v[m(i)] + f v[m(i+1)], m = mirror about the edge samples."""
+    img = np.asarray(img, np.float64)
+    h, w = img.shape
+    oh, ow = int(round(h * scale)), int(round(w * scale))
+
+    def axis(n, on):
+        x = (np.arange(on) + 0.5) * (n / on) - 0.5
+        i = np.floor(x).astype(np.int64)
+        f = x - i
+        period = max(2 * n - 2, 1)
+
+        def mirror(k):
+            k = np.mod(k, period)
+            return np.where(k < n, k, period - k) if n > 1 else np.zeros_like(k)
+
+        return mirror(i), mirror(i + 1), f
+
+    y0, y1, fy = axis(h, oh)
+    x0, x1, fx = axis(w, ow)
+    rows = (1 - fy)[:, None] * img[y0, :] + fy[:, None] * img[y1, :]
+    return (1 - fx)[None, :] * rows[:, x0] + fx[None, :] * rows[:, x1]
+
+
+def calculate_contrast(cancer_loc, contralateral_loc, noise_loc, scale, image, focus):
+    """nn_mri.py:59-85 restated (C, CNR, CNR2 of 2*scale-wide squares); pinned by tests/golden/contrast.npz."""
+    def area(loc):
+        x, y = ((int(i) - focus) * scale for i in loc)
+        return np.asarray(image)[x - scale:x + scale, y - scale:y + scale]
+    ca, cb, cn = area(cancer_loc), area(contralateral_loc), area(noise_loc)
+    diff = abs(ca.mean() - cb.mean())
+    return ca.mean() / (cb.mean() + 1e-7), diff / np.sqrt(np.std(ca) ** 2 + np.std(cb) ** 2), diff / np.std(cn)

@@ -17,15 +17,16 @@ COST_RTOL = 1e-3        # |cost - cost_ref| <= COST_RTOL * cost_ref + COST_ATOL 
 COST_RTOL_FORKED = 1e-2  # and within 1 % on the forked ones (a different minimum, never a failed fit)
 COST_ATOL = 1e-6
 PARAM_RTOL = 1e-5       # max_k |x_k - ref_k| / max(1, |ref_k|) ...
-PARAM_FRACTION = 0.60   # ... on at least this fraction of voxels
-NFEV_FRACTION = 0.70    # identical number of function evaluations on at least this fraction
+PARAM_FRACTION = 0.68   # ... on at least this fraction of voxels.  Observed on the MI355X (round 2, printed by check_against):
+                        # 0.70 (60 driver voxels), 0.797 (the 128 golden voxels), 0.917 (72), 0.805 (200 noisy ones)
+NFEV_FRACTION = 0.84    # identical number of function evaluations on at least this fraction (observed 0.867 / 0.847 / 0.85)
 
 
 def pack(D, T2, v):
     return np.column_stack([D, T2, v[:, :2]])
 
 
-def check_against(x, x_ref, cost=None, cost_ref=None, nfev=None, nfev_ref=None):
+def check_against(x, x_ref, cost=None, cost_ref=None, nfev=None, nfev_ref=None, param_fraction=PARAM_FRACTION):
     curves = np.stack([P.three_compartment(p) for p in x])
     curves_ref = np.stack([P.three_compartment(p) for p in x_ref])
     sig_err = np.linalg.norm(curves - curves_ref, axis=1) / np.linalg.norm(curves_ref, axis=1)
@@ -33,7 +34,7 @@ def check_against(x, x_ref, cost=None, cost_ref=None, nfev=None, nfev_ref=None):
     assert same.mean() >= SIGNAL_FRACTION, f"fitted curves differ on {1 - same.mean():.3f} of the voxels"
     perr = np.max(np.abs(x - x_ref) / np.maximum(1.0, np.abs(x_ref)), axis=1)
     frac = float((perr <= PARAM_RTOL).mean())
-    assert frac >= PARAM_FRACTION, f"only {frac:.2f} of voxels agree in parameters"
+    assert frac >= param_fraction, f"only {frac:.2f} of voxels agree in parameters"
     assert np.all(x >= P.LB) and np.all(x <= P.UB)
     if cost is not None:
         ok = np.isfinite(cost_ref)

@@ -32,8 +32,8 @@ def test_full_size_stack_matches_oracle():
     got = model(x).cpu().numpy()
     assert got.shape == (2, 384, 384, 1)
     assert O.rel_l2((got - R.MEAN) / R.STD, (want - R.MEAN) / R.STD) < 5e-5
-    single = model(x[:1]).cpu().numpy()
-    assert np.array_equal(single, got[:1])                      # batch 1 (the reference's call shape) == slice of batch 2
+    single = model(x[:1]).cpu().numpy()                         # batch 1 is the reference's call shape (master.py:50)
+    assert O.rel_l2(single, got[:1]) < 1e-6                     # (pooled sums are reduced in a batch-dependent order)
     pt = rams.predict_tensor(model, x[:1]).cpu().numpy()
     ref = R.predict_tensor(params, x[:1])
     assert (pt != ref).mean() < 1e-2 and np.abs(pt - ref).max() <= 1.0
