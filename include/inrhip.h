@@ -222,6 +222,24 @@ int inr_ssim2d(double* out, const float* x, const float* y, int n_images, int he
                void* stream);
 int inr_adc_map(float* out, const float* data, const float* bvals, int64_t n_pixels, int n_b, void* stream);
 
+/* ---- a-15 / (f)-4: RAMS training step (utils/training.py:193-209 train_step; utils/loss.py:26-75 l1_loss; weight
+ * normalisation utils/network.py:29-35).  Parameters in the reference's own variables ("raw" layout): per layer, in graph
+ * order, v [taps * cin][cout] (the TensorFlow kernel [k..., cin, cout] flattened), g [cout], b [cout], every segment padded to
+ * 4 floats -- inr_rams_train_param_offsets returns the three offsets per layer (and the layer count).
+ * inr_rams_train_grads: forward (every intermediate kept) -> per-image cL1 loss[b] (double) -> d(sum_b loss[b]) / d params
+ * into `grads` (same layout); `pred` (nullable) receives the un-clipped prediction [B][scale*H][scale*W].
+ * x [B][H][W][9] fp32, y_true / mask [B][scale*H][scale*W] fp32, H == W.
+ * inr_rams_train_step: the same, then Adam in Keras' form (p -= lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)). */
+int64_t inr_rams_train_param_count(const inr_rams_desc_t* desc);
+int     inr_rams_train_param_offsets(const inr_rams_desc_t* desc, int64_t* offsets, int max_layers);
+size_t  inr_rams_train_workspace_bytes(const inr_rams_desc_t* desc, int batch, int height, int width);
+int inr_rams_train_grads(const inr_rams_desc_t* desc, const float* params, float* grads, const float* x, const float* y_true,
+                         const float* mask, double* loss, float* pred, int batch, int height, int width, void* workspace,
+                         size_t workspace_bytes, void* stream);
+int inr_rams_train_step(const inr_rams_desc_t* desc, float* params, float* grads, float* m, float* v, const float* x,
+                        const float* y_true, const float* mask, double* loss, int batch, int height, int width, int64_t step,
+                        double lr, double beta1, double beta2, double eps, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- (f)-2: per-voxel acquisition combinations (SRDWI.py:143-152 calculate_combinations, mapped over all voxels by a
  * 32-process pool at superresDWI.py:57-76).  raw_b0 [n_voxels], raw_bk [n_voxels][nk] (k = 1..3) fp32 ->
  * out [n_voxels][4][K], K = n1*n2*n3, combination index in itertools.product order (the last b-value's index fastest). */

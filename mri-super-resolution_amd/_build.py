@@ -16,7 +16,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libinrhip.so")
-SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "rams_train.hip", "siren_small.hip",
+SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "siren_small.hip",
            "hybrid_fit.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

@@ -87,6 +87,14 @@ SIGNATURES = {
     "inr_psnr": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_size_t, c_stream]),
     "inr_ssim2d": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                              C.c_float, C.c_void_p, C.c_size_t, c_stream]),
+    "inr_rams_train_param_count": (C.c_int64, [C.POINTER(RamsDesc)]),
+    "inr_rams_train_param_offsets": (C.c_int, [C.POINTER(RamsDesc), c_i64p, C.c_int]),
+    "inr_rams_train_workspace_bytes": (C.c_size_t, [C.POINTER(RamsDesc), C.c_int, C.c_int, C.c_int]),
+    "inr_rams_train_grads": (C.c_int, [C.POINTER(RamsDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_size_t, c_stream]),
+    "inr_rams_train_step": (C.c_int, [C.POINTER(RamsDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_void_p, C.c_size_t, c_stream]),
     "inr_acquisition_products": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            c_stream]),
     "inr_rescale2d_linear": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),

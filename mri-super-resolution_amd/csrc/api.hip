@@ -145,6 +145,11 @@ int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
                       int border, int mode, double* ws, hipStream_t st);
 long long rams_param_floats(const inr_rams_desc_t* d);
+long long rams_train_param_floats(const inr_rams_desc_t* d);
+int rams_train_param_offsets(const inr_rams_desc_t* d, int64_t* offsets, int max_layers);
+size_t rams_train_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W);
+int rams_train_grads(const inr_rams_desc_t* d, const float* raw, float* raw_grad, const float* x, const float* y_true,
+                     const float* mask, double* loss, float* pred, int B, int H, int W, float* ws, hipStream_t st);
 size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W);
 int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
                       int clip_round, float* ws, hipStream_t st);
@@ -1181,6 +1186,58 @@ int inr_prof_read(int kernel_class, int64_t* launches, double* total_ms) {
     *launches = (int64_t)g_prof.spans[kernel_class].size();
     *total_ms = ms;
     return 0;
+}
+
+// ---- a-15 / (f)-4: RAMS training step ------------------------------------------------------------------------------------------
+static int check_rams_train(const inr_rams_desc_t* desc, int B, int H, int W) {
+    INR_REQUIRE(desc != nullptr, INR_E_INVALID, "rams descriptor is null");
+    INR_REQUIRE(desc->filters == 32 && desc->kernel_size == 3 && desc->channels == 9 && desc->scale >= 1 && desc->scale <= 5 &&
+                    desc->r >= 1 && desc->n_rfab >= 0,
+                INR_E_INVALID, "rams train: supported configuration is filters 32, kernel 3, channels 9");
+    INR_REQUIRE(B >= 1 && H >= 3 && W >= 3 && H == W, INR_E_INVALID,
+                "rams train: batch >= 1 and square low-resolution patches (the loss of utils/loss.py works on squares)");
+    return 0;
+}
+
+int64_t inr_rams_train_param_count(const inr_rams_desc_t* desc) {
+    if (!desc) return INR_E_INVALID;
+    return rams_train_param_floats(desc);
+}
+
+int inr_rams_train_param_offsets(const inr_rams_desc_t* desc, int64_t* offsets, int max_layers) {
+    INR_REQUIRE(desc && offsets, INR_E_INVALID, "inr_rams_train_param_offsets: null pointer");
+    return rams_train_param_offsets(desc, offsets, max_layers);
+}
+
+size_t inr_rams_train_workspace_bytes(const inr_rams_desc_t* desc, int batch, int height, int width) {
+    if (!desc || batch < 1 || height < 3 || width < 3) return 0;
+    return rams_train_workspace_floats(desc, batch, height, width) * sizeof(float);
+}
+
+int inr_rams_train_grads(const inr_rams_desc_t* desc, const float* params, float* grads, const float* x, const float* y_true,
+                         const float* mask, double* loss, float* pred, int batch, int height, int width, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    if (int rc = check_rams_train(desc, batch, height, width)) return rc;
+    INR_REQUIRE(params && grads && x && y_true && mask && loss, INR_E_INVALID, "inr_rams_train_grads: null pointer");
+    INR_REQUIRE(workspace && workspace_bytes >= inr_rams_train_workspace_bytes(desc, batch, height, width), INR_E_WORKSPACE,
+                "inr_rams_train_grads: workspace too small");
+    INR_REQUIRE(aligned16(workspace) && aligned16(params) && aligned16(grads), INR_E_ALIGN,
+                "inr_rams_train_grads: params / grads / workspace must be 16-byte aligned");
+    return rams_train_grads(desc, params, grads, x, y_true, mask, loss, pred, batch, height, width, (float*)workspace,
+                            (hipStream_t)stream);
+}
+
+int inr_rams_train_step(const inr_rams_desc_t* desc, float* params, float* grads, float* m, float* v, const float* x,
+                        const float* y_true, const float* mask, double* loss, int batch, int height, int width, int64_t step,
+                        double lr, double beta1, double beta2, double eps, void* workspace, size_t workspace_bytes, void* stream) {
+    INR_REQUIRE(m && v && step >= 1, INR_E_INVALID, "inr_rams_train_step: Adam state missing or step < 1");
+    if (int rc = inr_rams_train_grads(desc, params, grads, x, y_true, mask, loss, nullptr, batch, height, width, workspace,
+                                      workspace_bytes, stream))
+        return rc;
+    // Keras Adam: p -= lr sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps)  ==  the kernel's form with eps / sqrt(1 - b2^t)
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    return launch_adam(params, grads, m, v, rams_train_param_floats(desc), step, lr, beta1, beta2, eps / sqrt(bc2),
+                       (hipStream_t)stream);
 }
 
 int inr_debug_set_ptr(int key, void* ptr) {

@@ -1087,7 +1087,8 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
 // host side of the pre-split path (gemm_hp.inc)
 // =====================================================================================================
 int g_hp_stagger = 0;      // inr_debug_set(11, n): start phases of the persistent blocks, n * 64 cycles apart (0 = together)
-int g_hp_persistent = 1;   // inr_debug_set(10, 0): one block per tile instead of the persistent walk
+int g_hp_persistent = 2;   // inr_debug_set(10, v): 2 persistent walk with the epilogue of tile T under the K-loop of tile T+1
+                           // (K = 256 / 512), 1 persistent walk with the epilogue in line, 0 one block per tile
 static int hp_num_cus() {
     static int n = 0;
     if (!n) {
@@ -1169,8 +1170,16 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
     const dim3 grid((unsigned)tiles), block(HP_NTH);
     p.stamps = hp_stamp_target(KC_GEMM_FWD);
     ProfScope ps(KC_GEMM_FWD, stream);
-    if (g_hp_persistent && in_f >= 3 * HP_BK) {
-        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+    const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+    if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
+        if (in_f == 512) {
+            if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 16>), pgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 16>), pgrid, block, 0, stream, p);
+        } else {
+            if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 8>), pgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 8>), pgrid, block, 0, stream, p);
+        }
+    } else if (g_hp_persistent && in_f >= 3 * HP_BK) {
         if (dact) hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE_STASH>), pgrid, block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE>), pgrid, block, 0, stream, p);
     } else if (dact) {
@@ -1199,8 +1208,10 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
     const dim3 grid((unsigned)tiles), block(HP_NTH);
     p.stamps = hp_stamp_target(KC_GEMM_DX);
     ProfScope ps(KC_GEMM_DX, stream);
-    if (g_hp_persistent && out_f >= 3 * HP_BK) {
-        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+    const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+    if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
+        hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_MUL, 16>), pgrid, block, 0, stream, p);
+    } else if (g_hp_persistent && out_f >= 3 * HP_BK) {
         hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_MUL>), pgrid, block, 0, stream, p);
     } else {
         hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);

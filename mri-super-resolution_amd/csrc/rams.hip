@@ -685,4 +685,6 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     return 0;
 }
 
+#include "rams_train.inc"
+
 }  // namespace inr

@@ -251,3 +251,104 @@ def conv3d_wgrad(x, dy, pad=1):
     check(lib().inr_rams_conv3d_wgrad(gw.data_ptr(), gb.data_ptr(), x.data_ptr(), dy.data_ptr(), B, D1, D2, D3, int(pad),
                                       ws.data_ptr(), ws.numel() * 4, ops._stream()), "inr_rams_conv3d_wgrad")
     return gw, gb
+
+
+# ---- the training step (utils/training.py:193-209) --------------------------------------------------------------------------
+class RamsTrainer:
+    """``Trainer.train_step`` of the reference (utils/training.py:193-209) on the device: forward with every intermediate
+    kept -> per-image cL1 (utils/loss.py:26-75) -> gradients of ``sum_b loss_b`` (what ``tape.gradient`` of the loss vector
+    is) with respect to every ``v``, ``g`` and bias -> Adam in Keras' form.  One C call per step (``inr_rams_train_step``).
+
+    The model's parameters live in one flat device buffer in the reference's variables (per layer ``v``, ``g``, ``b``:
+    the "raw" layout of include/inrhip.h); ``sync_model()`` writes them back into ``model.params`` (and drops the model's
+    packed inference copy)."""
+
+    def __init__(self, model: RAMS, learning_rate=5e-4, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        dev = ops.require_gpu()
+        self.model = model
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        total = lib().inr_rams_train_param_count(C.byref(model.desc))
+        if total < 0:
+            check(int(total), "inr_rams_train_param_count")
+        offs = (C.c_int64 * (3 * 128))()
+        n = lib().inr_rams_train_param_offsets(C.byref(model.desc), offs, 128)
+        if n != len(model.specs):
+            raise RuntimeError(f"library reports {n} layers, the model has {len(model.specs)}")
+        self.offsets = [(int(offs[3 * i]), int(offs[3 * i + 1]), int(offs[3 * i + 2])) for i in range(n)]
+        flat = np.zeros(int(total), np.float32)
+        for (name, ks, cin, cout), (ov, og, ob) in zip(model.specs, self.offsets):
+            v = np.asarray(model.params[f"{name}/v"], np.float32).reshape(-1)
+            flat[ov:ov + v.size] = v
+            flat[og:og + cout] = model.params[f"{name}/g"]
+            flat[ob:ob + cout] = model.params[f"{name}/b"]
+        self.flat = torch.from_numpy(flat).to(dev)
+        self.grads = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._ws = None
+
+    def _prep(self, lr_batch, hr, mask):
+        dev = self.flat.device
+
+        def as_dev(t, squeeze):
+            t = torch.as_tensor(np.asarray(t, np.float32) if not torch.is_tensor(t) else t).to(dev, torch.float32)
+            if squeeze and t.dim() == 4 and t.shape[-1] == 1:
+                t = t[..., 0]
+            return t.contiguous()
+
+        x = as_dev(lr_batch, False)                     # tf.cast(lr, tf.float32), training.py:195
+        yt, mk = as_dev(hr, True), as_dev(mask, True)
+        B, H, W, ch = x.shape
+        s = self.model.cfg["scale"]
+        if ch != self.model.cfg["channels"] or tuple(yt.shape) != (B, H * s, W * s) or tuple(mk.shape) != tuple(yt.shape):
+            raise ValueError(f"shapes: lr {tuple(x.shape)}, hr {tuple(yt.shape)}, mask {tuple(mk.shape)}")
+        need = lib().inr_rams_train_workspace_bytes(C.byref(self.model.desc), B, H, W)
+        if need == 0:
+            check(-1, "inr_rams_train_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return x, yt, mk, B, H, W
+
+    def loss_and_grads(self, lr_batch, hr, mask, want_prediction=False):
+        """Per-image loss [B] (float64) and ``d sum(loss) / d parameters`` (left in ``self.grads``); no update."""
+        x, yt, mk, B, H, W = self._prep(lr_batch, hr, mask)
+        s = self.model.cfg["scale"]
+        loss = torch.empty(B, dtype=torch.float64, device=x.device)
+        pred = torch.empty((B, H * s, W * s), dtype=torch.float32, device=x.device) if want_prediction else None
+        check(lib().inr_rams_train_grads(C.byref(self.model.desc), self.flat.data_ptr(), self.grads.data_ptr(), x.data_ptr(),
+                                         yt.data_ptr(), mk.data_ptr(), loss.data_ptr(), 0 if pred is None else pred.data_ptr(),
+                                         B, H, W, self._ws.data_ptr(), self._ws.numel(), ops._stream()), "inr_rams_train_grads")
+        return (loss, pred) if want_prediction else loss
+
+    def train_step(self, lr_batch, hr, mask):
+        """One optimizer step; returns the per-image loss vector the reference feeds to ``train_loss`` (training.py:207)."""
+        x, yt, mk, B, H, W = self._prep(lr_batch, hr, mask)
+        loss = torch.empty(B, dtype=torch.float64, device=x.device)
+        self.step_count += 1
+        check(lib().inr_rams_train_step(C.byref(self.model.desc), self.flat.data_ptr(), self.grads.data_ptr(), self.m.data_ptr(),
+                                        self.v.data_ptr(), x.data_ptr(), yt.data_ptr(), mk.data_ptr(), loss.data_ptr(), B, H, W,
+                                        self.step_count, self.lr, self.b1, self.b2, self.eps, self._ws.data_ptr(),
+                                        self._ws.numel(), ops._stream()), "inr_rams_train_step")
+        self.model.invalidate()
+        return loss
+
+    def named_gradients(self):
+        """{``<layer>/v|g|b``: ndarray} views of the last gradient, in the reference's variable shapes."""
+        g = self.grads.cpu().numpy()
+        return self._unflatten(g)
+
+    def _unflatten(self, flat):
+        out = {}
+        for (name, ks, cin, cout), (ov, og, ob) in zip(self.model.specs, self.offsets):
+            n = int(np.prod(ks)) * cin * cout
+            out[f"{name}/v"] = flat[ov:ov + n].reshape(tuple(ks) + (cin, cout)).copy()
+            out[f"{name}/g"] = flat[og:og + cout].copy()
+            out[f"{name}/b"] = flat[ob:ob + cout].copy()
+        return out
+
+    def sync_model(self):
+        self.model.params = self._unflatten(self.flat.cpu().numpy())
+        self.model.invalidate()
+        return self.model

@@ -182,3 +182,42 @@ def shift_losses(y_true, y_pred, y_mask, size, border=3):
             l1s.append(np.abs(lm - corr).sum(axis=(1, 2)) / tot)
             ps.append(10.0 * np.log10(65535.0 ** 2 / (((lm - corr) ** 2).sum(axis=(1, 2)) / tot)))
     return np.min(np.stack(l1s), axis=0), np.max(np.stack(ps), axis=0)
+
+
+def shift_l1_torch(y_true, y_pred, y_mask, size, border=3):
+    """utils/loss.py:26-75 on torch tensors [B, size, size] (differentiable; float64 recommended): per-image minimum over
+    the 7 x 7 label shifts of the brightness-corrected masked L1."""
+    c = size - 2 * border
+    pred = y_pred[:, border:size - border, border:size - border]
+    vals = []
+    for i in range(2 * border + 1):
+        for j in range(2 * border + 1):
+            lab = y_true[:, i:i + c, j:j + c]
+            m = y_mask[:, i:i + c, j:j + c]
+            pm, lm = pred * m, lab * m
+            tot = m.sum(dim=(1, 2))
+            b = ((lm - pm).sum(dim=(1, 2)) / tot)[:, None, None]
+            corr = (pm + b) * m
+            vals.append((lm - corr).abs().sum(dim=(1, 2)) / tot)
+    return torch.stack(vals).min(dim=0).values
+
+
+def train_grads(params, x, y_true, y_mask, dtype=torch.float64, **kw):
+    """Trainer.train_step's gradient (utils/training.py:193-209) by autograd on this restatement: returns (per-image loss,
+    {name: d sum(loss) / d variable})."""
+    tp = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True) for k, v in params.items()}
+    xt = torch.as_tensor(np.asarray(x), dtype=dtype)
+    sr = rams_graph(tp, xt, **kw)[..., 0]
+    size = sr.shape[1]
+    loss = shift_l1_torch(torch.as_tensor(np.asarray(y_true), dtype=dtype), sr, torch.as_tensor(np.asarray(y_mask), dtype=dtype), size)
+    loss.sum().backward()
+    return loss.detach().numpy(), {k: v.grad.numpy() for k, v in tp.items()}
+
+
+def keras_adam_step(params, grads, m, v, t, lr=5e-4, b1=0.9, b2=0.999, eps=1e-7):
+    """Keras Adam (non-amsgrad), in place on float64 dicts: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); p -= lr_t m / (sqrt(v) + eps)."""
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    for k in params:
+        m[k] = b1 * m[k] + (1 - b1) * grads[k]
+        v[k] = b2 * v[k] + (1 - b2) * grads[k] ** 2
+        params[k] = params[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)

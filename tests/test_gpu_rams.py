@@ -162,3 +162,57 @@ def test_conv3d_forward_and_gradients_vs_torch(shape, pad):
     if pad == 1:
         dx = rams.conv3d_dgrad(dy_dev, w.cuda())
         assert rel(dx.cpu().numpy(), xr.grad.permute(0, 2, 3, 4, 1).numpy()) < 5e-6
+
+
+def _train_case(B=2, side=20, seed=3):
+    rng = np.random.default_rng(seed)
+    x = (rng.random((B, side, side, 9)) * 20000 + 2000).astype(np.float32)
+    hr = (rng.random((B, 3 * side, 3 * side)) * 20000 + 2000).astype(np.float32)
+    mask = (rng.random((B, 3 * side, 3 * side)) > 0.15).astype(np.float32)
+    return x, hr, mask
+
+
+def test_train_gradients_match_autograd():
+    """Trainer.train_step (utils/training.py:193-209): gradients of all 71 layers (v, g, b: 213 tensors) of a (2, 20, 20, 9)
+    batch against torch autograd on the float64 restatement (itself unpinned against TensorFlow -- see the oracle)."""
+    params = R.init_rams_params(seed=5, perturb_g=True)
+    model = rams.RAMS(3, 32, 3, 9, 8, 12, params=params)
+    x, hr, mask = _train_case()
+    want_loss, want = R.train_grads(params, x, hr, mask)
+    trainer = rams.RamsTrainer(model)
+    loss, pred = trainer.loss_and_grads(x, hr, mask, want_prediction=True)
+    assert O.rel_l2(pred.cpu().numpy(), R.rams_forward(params, x)[..., 0]) < 1e-5
+    assert np.allclose(loss.cpu().numpy(), want_loss, rtol=1e-5)
+    got = trainer.named_gradients()
+    assert set(got) == set(want) and len(got) == 213
+    worst = max((O.rel_l2(got[k], want[k]), k) for k in want if np.linalg.norm(want[k]) > 0)
+    assert worst[0] < 1e-4, worst                                  # fp32 pipeline (exact-fp32 MFMA) vs float64 autograd
+    total = O.rel_l2(np.concatenate([got[k].reshape(-1) for k in sorted(want)]),
+                     np.concatenate([want[k].reshape(-1) for k in sorted(want)]))
+    assert total < 1e-5, total
+
+
+def test_train_steps_follow_keras_adam():
+    """Ten train_steps on a small RAMS (N = 2): the loss trajectory against the float64 restatement + Keras-form Adam."""
+    params = R.init_rams_params(seed=6, perturb_g=True, N=2)
+    model = rams.RAMS(3, 32, 3, 9, 8, 2, params={k: v.copy() for k, v in params.items()})
+    x, hr, mask = _train_case(B=2, side=16, seed=8)
+    trainer = rams.RamsTrainer(model, learning_rate=5e-4)
+    got = [float(trainer.train_step(x, hr, mask).sum()) for _ in range(10)]
+    p = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v2 = {k: np.zeros_like(v) for k, v in p.items()}
+    want = []
+    for t in range(1, 11):
+        loss, g = R.train_grads(p, x, hr, mask, N=2)
+        want.append(float(loss.sum()))
+        R.keras_adam_step(p, g, m, v2, t)
+    # Adam divides by sqrt(v): parameters whose gradient is round-off get steps of full size in a direction set by that
+    # round-off, so fp32-vs-float64 differences grow with the step count (observed 2e-8, 5e-8, 7e-8, 1e-6, 1e-5, 9e-5, ...)
+    assert np.allclose(got[:5], want[:5], rtol=1e-4), (got, want)
+    assert np.allclose(got, want, rtol=5e-3), (got, want)
+    assert got[-1] < got[0]
+    synced = trainer.sync_model()
+    assert O.rel_l2(synced.params["rfab1/conv2/v"], p["rfab1/conv2/v"]) < 5e-3   # (observed 1.5e-3 after 10 Adam steps)
+    out = synced(x).cpu().numpy()                                  # the inference path picks the trained weights up
+    assert O.rel_l2(out, R.rams_forward({k: v.astype(np.float32) for k, v in p.items()}, x, N=2)) < 5e-3

@@ -39,3 +39,13 @@ if ok.any():
     for q in (10, 50, 90):
         print(f"   p{q}: X {np.percentile(s[ok,6]-s[ok,5], q):.0f}  Y {np.percentile(s[ok,7]-s[ok,6], q):.0f}  barrier {np.percentile(s[ok,8]-s[ok,7], q):.0f}  Z {np.percentile(s[ok,9]-s[ok,8], q):.0f}")
 # blocks per CU over time: how many tiles does a CU run back to back, and how long is the gap between them
+
+# deferred-epilogue kernel (gemm_hp_pkd): iterations 6 (waves 0-3 convert a chunk) and 7 (waves 4-7 do), per wave half
+w = np.arange(len(s)) % 8
+for name, base in (("iteration 6", 5), ("iteration 7", 10)):
+    okk = s[:, base] > 0
+    if not okk.any():
+        continue
+    for half, sel in (("waves 0-3", okk & (w < 4)), ("waves 4-7", okk & (w >= 4))):
+        d = [med(s[sel, base + k + 1] - s[sel, base + k]) for k in range(4)]
+        print(f"{name} {half}: X {d[0]:.0f} | wait+barrier {d[1]:.0f} | chunk {d[2]:.0f} | Z+Y {d[3]:.0f} | total {sum(d):.0f}")
