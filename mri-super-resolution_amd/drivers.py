@@ -233,13 +233,38 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
 RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss")
 
 
+def hybrid_te_groups(world_size: int) -> List[List[int]]:
+    """Which ranks fit which of the four echo times (superresHybrid.py:79): with four or more ranks every TE gets its own
+    contiguous group (8 ranks: pairs, each pair row-shards its fit); with fewer, TE ``t`` goes to rank ``t % world``."""
+    if world_size >= 4:
+        return inr_dist._split_ranks(world_size, [1.0] * 4)
+    return [[te % max(world_size, 1)] for te in range(4)]
+
+
+def _sum_over_ranks(t: torch.Tensor) -> None:
+    if torch.distributed.get_backend() == "nccl":
+        torch.distributed.all_reduce(t)
+    else:
+        h = t.cpu()
+        torch.distributed.all_reduce(h)
+        t.copy_(h)
+
+
 def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slice_index: Optional[int] = None,
-               steps: int = 2500, seed: Optional[int] = 0, **fit_kwargs) -> Dict[str, object]:
+               steps: int = 2500, seed: Optional[int] = 0, distributed: bool = False, gather_recon: bool = False,
+               target_dtype=None, **fit_kwargs) -> Dict[str, object]:
     """superresHybrid.py:57-140.  ``hybrid_raw``: [X, Y, Z, 4 (b), 4 (TE)].  Per echo time one 4-D INR fit of the
     ROI (LR = every second in-plane voxel, coordinates (x, y, z, b)), re-sampled at twice the ROI size; the 16
     re-scaled images are normalised by the (b=0, TE=0) one (x1000) and one z-slice goes through the three-compartment
     fit.  Returns the device tensor ``recon_hybrid`` [2sx, 2sy, Z, 4, 4] and numpy maps ``D``, ``T2``, ``v``
-    [2sx, 2sy, 3] plus timings."""
+    [2sx, 2sy, 3] plus timings.
+
+    ``distributed=True`` (inside an initialised process group): the four TE fits are independent, so they are placed on the
+    ranks by ``hybrid_te_groups`` (a group of several ranks row-shards its fit); the only exchange is ONE all-reduce of
+    the z-slice that feeds the three-compartment fit ([2sx, 2sy, 4, 4]; every rank contributes the echo times it owns,
+    zeros elsewhere), after which every rank runs the same hybrid fit.  ``recon_hybrid`` holds the owned echo times only
+    unless ``gather_recon`` asks for a second all-reduce of the whole tensor.
+    ``target_dtype=np.float16``: the normalised volume is held in half precision (BASELINE config 5) and widened per fit."""
     from . import pia
     raw = np.asarray(hybrid_raw, dtype=np.float32)
     if raw.ndim != 5 or raw.shape[3] != 4 or raw.shape[4] != 4:
@@ -252,18 +277,42 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
     scale = torch.from_numpy(maxes).cuda()
     t_fit = t_recon = 0.0
     losses = []
+    if target_dtype is not None:
+        norm = norm.astype(target_dtype)
+    spread = distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    rank = torch.distributed.get_rank() if spread else 0
+    te_ranks = hybrid_te_groups(torch.distributed.get_world_size()) if spread else [[0]] * 4
+    # (new_group is collective over the default group: every rank creates every group, in the same order)
+    te_groups = [torch.distributed.new_group(r) if spread and len(r) > 1 else None for r in te_ranks]
+    if spread:
+        recon_hybrid.zero_()
+    owned = []
     for te in range(4):                                                                    # superresHybrid.py:79
-        vol = np.ascontiguousarray(norm[x0:x1, y0:y1, :, :, te])                           # (x, y, z, b)
+        if rank not in te_ranks[te]:
+            losses.append(float("nan"))
+            continue
+        vol = np.ascontiguousarray(norm[x0:x1, y0:y1, :, :, te], dtype=np.float32)         # (x, y, z, b)
         res = fit_volume(vol, steps=steps, seed=None if seed is None else seed + te, evaluate=False, normalize=False,
-                         **fit_kwargs)
-        recon_hybrid[..., te] = res["recon"] * scale[:, te]                                # superresHybrid.py:121-122
+                         group=te_groups[te], **fit_kwargs)
         t_fit += res["t_fit"]
         t_recon += res["t_recon"]
         losses.append(res["final_loss"])
+        if not res.get("partner"):
+            recon_hybrid[..., te] = res["recon"] * scale[:, te]                            # superresHybrid.py:121-122
+            owned.append(te)
     k = nz // 2 if slice_index is None else int(slice_index)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    sl = recon_hybrid[:, :, k].double()                                                    # [2sx, 2sy, 4, 4]
+    if spread:
+        if gather_recon:
+            _sum_over_ranks(recon_hybrid)
+            sl = recon_hybrid[:, :, k].double()
+        else:
+            plane = recon_hybrid[:, :, k].contiguous()                                     # owned echo times, zeros elsewhere
+            _sum_over_ranks(plane)
+            sl = plane.double()
+    else:
+        sl = recon_hybrid[:, :, k].double()                                                # [2sx, 2sy, 4, 4]
     signals = (1000.0 * sl / (sl[..., 0:1, 0:1] + 1e-7)).reshape(-1, 16)                   # superresHybrid.py:131-138
     fit = pia.hybrid_fit_device(signals)
     x = fit["params"].cpu().numpy()
@@ -272,7 +321,7 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
     v = np.concatenate([x[:, 6:8], 1 - x[:, 6:7] - x[:, 7:8]], axis=1)
     return {"recon_hybrid": recon_hybrid, "signals": signals, "D": x[:, 0:3].reshape(shape), "T2": x[:, 3:6].reshape(shape),
             "v": v.reshape(shape), "status": fit["status"].cpu().numpy().reshape(shape[:2]), "t_fit": t_fit,
-            "t_recon": t_recon, "t_hybrid_fit": t_hybrid, "final_losses": losses, "slice_index": k}
+            "t_recon": t_recon, "t_hybrid_fit": t_hybrid, "final_losses": losses, "slice_index": k, "owned_te": owned}
 
 
 def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True,

@@ -83,3 +83,16 @@ def _failing_worker(rank, world):
 def test_harness_reports_a_dead_rank_instead_of_hanging():
     with pytest.raises(AssertionError, match="rank 1 dies"):
         run_ranks(_failing_worker, 2, timeout=60)
+
+
+def test_hybrid_echo_time_groups():
+    """superresHybrid.py:79's four TE fits over 1..8 ranks: every TE has an owner group, groups are disjoint and contiguous
+    once there are four ranks, 8 ranks give four pairs."""
+    from mri_super_resolution_amd import drivers
+    assert drivers.hybrid_te_groups(1) == [[0]] * 4
+    assert drivers.hybrid_te_groups(3) == [[0], [1], [2], [0]]
+    assert drivers.hybrid_te_groups(4) == [[0], [1], [2], [3]]
+    assert drivers.hybrid_te_groups(8) == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    for w in (5, 6, 7):
+        g = drivers.hybrid_te_groups(w)
+        assert sorted(r for grp in g for r in grp) == list(range(w)) and all(len(grp) >= 1 for grp in g)

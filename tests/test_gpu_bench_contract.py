@@ -32,3 +32,24 @@ def test_bench_line_schema():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_bench_two_ranks_rehearsal_gloo():
+    """The N > 1 launch exactly as the driver does it (torch.distributed.run, one rank per "GPU"), rehearsed with both ranks
+    on the one test card and gloo standing in for RCCL: one line from rank 0, whole-job value over both ranks."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, INR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 524288 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)   # both ranks' rows / max time
+    assert "cpu_baseline" not in d        # rank 0 times the CPU baseline at N = 1 only

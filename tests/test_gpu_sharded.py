@@ -117,3 +117,42 @@ def test_run_volumes_unseeded_ranks_still_agree():
     assert recs0 == recs1 and [int(r["job"]) for r in recs0] == [0, 1, 2]
     assert all(np.isfinite(r["final_loss"]) and np.isfinite(r["psnr_db"]) for r in recs0)
     assert recs0[1]["psnr_db"] > 8.0 and recs0[1]["final_loss"] < 0.2    # 40 steps from an arbitrary draw: a fit, not noise
+
+
+def _hybrid_phantom():
+    X, Y, Z = 20, 16, 3
+    gx, gy = np.meshgrid(np.linspace(0, 1, X), np.linspace(0, 1, Y), indexing="ij")
+    amp = 500.0 * (1.0 + 0.3 * np.sin(3 * gx) * np.cos(2 * gy))
+    decay = np.exp(-np.arange(4)[:, None] * 0.35 - np.arange(4)[None, :] * 0.25)               # [b, TE]
+    return (amp[:, :, None, None, None] * decay * np.linspace(1.0, 0.9, Z).reshape(1, 1, Z, 1, 1)).astype(np.float32)
+
+
+HYBRID_KW = dict(roi=(2, 18, 2, 14), slice_index=1, steps=60, seed=0, hidden_features=64, hidden_layers=1, mapping_size=16)
+
+
+def _hybrid_worker(rank, world, half):
+    from mri_super_resolution_amd import drivers
+    res = drivers.fit_hybrid(_hybrid_phantom(), distributed=True, target_dtype=np.float16 if half else None, **HYBRID_KW)
+    return {"owned": res["owned_te"], "signals": res["signals"].cpu().numpy(), "D": res["D"], "T2": res["T2"], "v": res["v"],
+            "recon": res["recon_hybrid"].cpu().numpy()}
+
+
+def test_fit_hybrid_echo_times_spread_over_ranks():
+    """Config 5's structure (superresHybrid.py:79): the four TE fits are independent, two ranks take two each; ONE all-reduce
+    of the fitted z-slice, then both ranks hold the same signals and compartment maps as a single-process run."""
+    from mri_super_resolution_amd import drivers
+    assert drivers.hybrid_te_groups(2) == [[0], [1], [0], [1]]
+    want = drivers.fit_hybrid(_hybrid_phantom(), **HYBRID_KW)
+    r0, r1 = run_ranks(_hybrid_worker, 2, (False,), timeout=300)
+    assert r0["owned"] == [0, 2] and r1["owned"] == [1, 3]
+    ws = want["signals"].cpu().numpy()
+    for r in (r0, r1):
+        assert np.array_equal(r["signals"], ws)                                  # same kernels, same seeds: bitwise
+        for key in ("D", "T2", "v"):
+            assert np.array_equal(r[key], want[key])
+    wr = want["recon_hybrid"].cpu().numpy()
+    assert np.array_equal(r0["recon"][..., [0, 2]], wr[..., [0, 2]]) and not r0["recon"][..., [1, 3]].any()
+    assert np.array_equal(r1["recon"][..., [1, 3]], wr[..., [1, 3]])
+    # half-precision target storage (BASELINE config 5): the same flow from a float16 copy of the normalised volume
+    h0, _ = run_ranks(_hybrid_worker, 2, (True,), timeout=300)
+    assert np.abs(h0["signals"] - ws).max() / np.abs(ws).max() < 5e-3
