@@ -196,6 +196,16 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
                   int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps,
                   float* losses, void* workspace, size_t workspace_bytes, void* stream);
 
+/* a-11 / master.py:137-148: the same loop when the target (and weight) image changes every step -- `targets` and
+ * `weights` (nullable) hold n_acq images of n*out_features floats back to back, step `it` fits image
+ * (first_acq + it) % n_acq.  inr_siren_fit is the n_acq = 1 case.  For small networks (hidden 32 or 64, <= 32 inputs,
+ * one output, n <= 16,384) all steps run inside ONE persistent cooperative launch per 64 steps (grid barriers between
+ * the backward pass, the fixed-order gradient reduction + Adam, and the next forward): no launch per step at all. */
+int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grads, float* m, float* v,
+                        const float* x, const float* targets, const float* weights, int n_acq, int first_acq,
+                        int64_t n, int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps,
+                        float* losses, void* workspace, size_t workspace_bytes, void* stream);
+
 /* (e) one fit split over several GPUs: forward + loss + backward of THIS rank's row shard, no optimizer.
  * The mean of the loss runs over count_total elements (0 = n*out_features, i.e. an unsplit fit), so gradients and
  * losses of the shards add up to the full-batch step: all-reduce(sum) `grads` (flat, inr_siren_param_count floats)
@@ -330,7 +340,11 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * hi/lo-split operands per fp32 product, fp32 accumulate; default), 0 = f32-input MFMA, 2 = split-fp16 also in the
  * stand-alone layer calls (needs a >= 32 MiB device scratch buffer via inr_debug_set_ptr(1, ptr)); key 5 = serpentine
  * row-tile order between consecutive GEMMs (1 default, 0 off); key 6 = 128 x 256 tiles for the forward GEMMs (1
- * default, 0 = 128 x 128) */
+ * default, 0 = 128 x 128); key 7 = pre-split (HL32) operand path of the fused entry points (1 default); key 10 = its
+ * kernel family (2 = persistent with deferred epilogue, default; 1 = persistent, epilogue in line; 0 = one block per
+ * tile); key 11 = start stagger between CUs of the persistent kernels (K-steps x 100, 0 default); key 12 = small-network
+ * fit (1 = persistent multi-step kernel, default; 0 = two launches per step); keys 8/9 = time-stamp selection of
+ * diagnostic builds */
 int inr_debug_set(int key, int value);
 int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds);
                                                  key 1: device scratch for debug key 3 = 2 */

@@ -83,6 +83,9 @@ SIGNATURES = {
     "inr_siren_fit": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                 C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                 c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "inr_siren_fit_cycle": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+                                      C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "inr_metric_workspace_bytes": (C.c_size_t, [C.c_int]),
     "inr_psnr": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int64, C.c_double, C.c_void_p, C.c_size_t, c_stream]),
     "inr_ssim2d": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

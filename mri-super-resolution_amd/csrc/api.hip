@@ -155,10 +155,18 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
                       int clip_round, float* ws, hipStream_t st);
 bool small_path_ok(const inr_siren_desc_t* d, int64_t n);
 size_t small_workspace_floats(const inr_siren_desc_t* d, int64_t n, long long P);
+bool small_multi_ok(const inr_siren_desc_t* d, int64_t n);
+size_t small_multi_workspace_floats(const inr_siren_desc_t* d, int64_t n, long long P);
+int small_fit_multi(const inr_siren_desc_t* d, const long long* w_off, const long long* b_off, long long P, float* params,
+                    float* grads, float* m, float* v, const float* x, const float* targets, const float* weights, int n_acq,
+                    int first_acq, int64_t n, int64_t first_step, int n_steps, double lr, double b1, double b2, double eps,
+                    float* losses, float* ws, hipStream_t st);
 int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long long* b_off, long long P, float* params,
                    float* grads, float* m, float* v, const float* x, const float* target, const float* weight, int64_t n,
                    int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
 extern int g_force_generic;
+extern int g_small_rows;
+int g_small_multi = 1;   // small networks: 1 = persistent multi-step kernel (default), 0 = two launches per step
 extern int g_mfma16;
 extern int g_h3;
 extern int g_h3_wide;
@@ -718,6 +726,10 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     if (small_path_ok(d, n)) {   // the fused small-network step carves the same workspace differently
         const size_t small = round_up(small_workspace_floats(d, n, L.total) * sizeof(float), 256);
         if (small > c.total) c.total = small;
+        if (small_multi_ok(d, n)) {
+            const size_t multi = round_up(small_multi_workspace_floats(d, n, L.total) * sizeof(float), 256);
+            if (multi > c.total) c.total = multi;
+        }
     }
     return c;
 }
@@ -865,10 +877,11 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
 
 // per call: scales of the network input and of the targets, HL32 image of x
 static int hp_prepare_call(const H3Ctx& ctx, const Layout& L, char* xhl, const float* x, const float* target,
-                           const float* weight, int64_t n, int out_f, hipStream_t st) {
-    if (int rc = h3_tensor_amax(ctx.slots + 25, target, (long long)n * out_f, st, 0u)) return rc;
+                           const float* weight, int64_t n, int out_f, hipStream_t st, int64_t n_acq = 1) {
+    // (several acquisitions behind one pointer: the bounds cover all of them)
+    if (int rc = h3_tensor_amax(ctx.slots + 25, target, (long long)n * n_acq * out_f, st, 0u)) return rc;
     if (weight) {
-        if (int rc = h3_tensor_amax(ctx.slots + 26, weight, (long long)n * out_f, st, 0u)) return rc;
+        if (int rc = h3_tensor_amax(ctx.slots + 26, weight, (long long)n * n_acq * out_f, st, 0u)) return rc;
     }
     HpScale sx;
     sx.meas = ctx.slots + 24;
@@ -886,10 +899,23 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
                   const float* target, const float* weight, int64_t n, int64_t first_step, int n_steps, double lr,
                   double beta1, double beta2, double eps, float* losses, void* workspace, size_t workspace_bytes,
                   void* stream) {
+    return inr_siren_fit_cycle(desc, params, grads, m, v, x, target, weight, 1, 0, n, first_step, n_steps, lr, beta1, beta2,
+                               eps, losses, workspace, workspace_bytes, stream);
+}
+
+int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grads, float* m, float* v, const float* x,
+                        const float* targets, const float* weights, int n_acq, int first_acq, int64_t n,
+                        int64_t first_step, int n_steps, double lr, double beta1, double beta2, double eps, float* losses,
+                        void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(desc)) return rc;
+    const float* target = targets;
+    const float* weight = weights;
     INR_REQUIRE(params && grads && m && v && x && target, INR_E_INVALID, "inr_siren_fit: null pointer");
     INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_fit: bad row count %lld", (long long)n);
     INR_REQUIRE(first_step >= 1 && n_steps >= 0, INR_E_INVALID, "inr_siren_fit: first_step >= 1, n_steps >= 0");
+    INR_REQUIRE(n_acq >= 1 && first_acq >= 0 && first_acq < n_acq, INR_E_INVALID,
+                "inr_siren_fit_cycle: need n_acq >= 1 and 0 <= first_acq < n_acq");
+    const int64_t acq_stride = n * desc->out_features;      // floats between consecutive acquisitions
     const Layout L = make_layout(desc);
     const FitCarve c = fit_carve(desc, L, n);
     INR_REQUIRE(workspace && workspace_bytes >= c.total, INR_E_WORKSPACE,
@@ -913,10 +939,14 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
         // launch per step instead of ~45 layer-wise launches (csrc/siren_small.hip)
         long long w_off[32], b_off[32];
         for (int l = 0; l <= L.n_sine; ++l) { w_off[l] = L.w_off[l]; b_off[l] = L.b_off[l]; }
+        if (g_small_multi && small_multi_ok(desc, n))   // all steps inside one persistent launch per 64 steps
+            return small_fit_multi(desc, w_off, b_off, L.total, params, grads, m, v, x, targets, weights, n_acq, first_acq, n,
+                                   first_step, n_steps, lr, beta1, beta2, eps, losses, (float*)workspace, st);
         for (int it = 0; it < n_steps; ++it) {
-            if (int rc = small_fit_step(desc, w_off, b_off, L.total, params, grads, m, v, x, target, weight, n,
-                                        first_step + it, lr, beta1, beta2, eps, losses ? losses + it : nullptr,
-                                        (float*)workspace, st))
+            const int64_t a = (first_acq + it) % n_acq;
+            if (int rc = small_fit_step(desc, w_off, b_off, L.total, params, grads, m, v, x, targets + a * acq_stride,
+                                        weights ? weights + a * acq_stride : nullptr, n, first_step + it, lr, beta1,
+                                        beta2, eps, losses ? losses + it : nullptr, (float*)workspace, st))
                 return rc;
         }
         return 0;
@@ -930,9 +960,12 @@ int inr_siren_fit(const inr_siren_desc_t* desc, float* params, float* grads, flo
     const bool hp = hp_eligible(desc, L);
     char* xhl = base + c.xhl_off;
     if (hp && n_steps > 0) {
-        if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, st)) return rc;
+        if (int rc = hp_prepare_call(h3, L, xhl, x, targets, weights, n, desc->out_features, st, n_acq)) return rc;
     }
     for (int it = 0; it < n_steps; ++it) {
+        const int64_t a = (first_acq + it) % n_acq;
+        target = targets + a * acq_stride;
+        weight = weights ? weights + a * acq_stride : nullptr;
         if (hp) {
             if (int rc = fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, 0,
                                                  losses ? (losses + it) : loss_sink, st, h3))
@@ -1254,6 +1287,8 @@ int inr_debug_set(int key, int value) {
     if (key == 6) { g_h3_wide = value; return 0; }
     if (key == 7) { g_hp = value; return 0; }
     if (key == 10) { g_hp_persistent = value; return 0; }
+    if (key == 12) { g_small_multi = value; return 0; }
+    if (key == 13) { g_small_rows = value; return 0; }
     if (key == 11) { g_hp_stagger = value; return 0; }
     if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...
     if (key == 9) { g_stamp_nth = value; return 0; }     // ... and only the n-th one since this call (counts down)

@@ -206,17 +206,22 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
         torch.manual_seed(seed)
     model = Siren(2, hidden_features, hidden_layers, 1).cuda()
     coords = ImageFitting_set([imgs[0]]).coords[0]                        # get_mgrid(side, 2)
-    targets = [(2.0 * torch.from_numpy(a) - 1.0).reshape(-1, 1).cuda() for a in imgs]
-    wts = None if weights is None else [torch.from_numpy(np.asarray(w, np.float32)).reshape(-1, 1).cuda()
-                                        for w in weights]
+    # all acquisitions resident as ONE [K, N] tensor: a whole epoch (one weighted Adam step per acquisition) -- and every
+    # epoch before the averaging window -- is a single call (inr_siren_fit_cycle), not 2 K launches per epoch
+    targets = torch.stack([(2.0 * torch.from_numpy(a) - 1.0).reshape(-1) for a in imgs]).cuda()
+    wts = None if weights is None else torch.stack([torch.from_numpy(np.asarray(w, np.float32)).reshape(-1)
+                                                    for w in weights]).cuda()
+    n_acq = len(imgs)
     fitter = SirenFitter(model, lr=lr)
     predicted = torch.zeros(side, side, dtype=torch.float64, device="cuda")
     large = torch.zeros(side * scale, side * scale, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for step in range(total_steps):
-        for k, tgt in enumerate(targets):
-            fitter.step(coords, tgt, 1, None if wts is None else wts[k])
+    quiet = max(0, total_steps - seg)                                     # epochs before the first snapshot
+    if quiet:
+        fitter.step_cycle(coords, targets, quiet * n_acq, wts)
+    for step in range(quiet, total_steps):
+        fitter.step_cycle(coords, targets, n_acq, wts)
         if step >= total_steps - seg:                                     # master.py:149-160
             predicted += reconstruct(model, (side, side), None, clamp_min=None).double()
             large += reconstruct(model, (side * scale, side * scale), None, clamp_min=None).double()
@@ -226,8 +231,8 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
     # when total_steps >= seg); `divide_by` reproduces that literally
     n_snap = divide_by if divide_by is not None else min(seg, total_steps)
     return {"predicted": (predicted / max(n_snap, 1)).cpu().numpy(), "large": (large / max(n_snap, 1)).cpu().numpy(),
-            "seconds": dt, "optimizer_steps": total_steps * len(targets),
-            "train_voxels_per_s": total_steps * len(targets) * side * side / dt, "model": model}
+            "seconds": dt, "optimizer_steps": total_steps * n_acq,
+            "train_voxels_per_s": total_steps * n_acq * side * side / dt, "model": model}
 
 
 RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss")

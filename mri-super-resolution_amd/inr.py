@@ -348,6 +348,24 @@ class SirenFitter:
         self.step_count += int(n_steps)
         return losses[:n_steps]
 
+    def step_cycle(self, model_input, targets, n_steps, weights=None, first_acq=0):
+        """``n_steps`` steps whose target (and weight) image changes every step (master.py:137-148): ``targets`` /
+        ``weights`` are [n_acq, N] device tensors, step ``it`` fits acquisition ``(first_acq + it) % n_acq``.  One call into
+        ``inr_siren_fit_cycle`` -- for the small master.py networks one persistent launch per 64 steps."""
+        self._check_views()
+        x = model_input.detach().reshape(-1, model_input.shape[-1]).contiguous()
+        t = targets.detach().reshape(targets.shape[0], -1).contiguous()
+        w = None if weights is None else weights.detach().reshape(weights.shape[0], -1).contiguous()
+        losses = torch.empty(max(int(n_steps), 1), dtype=torch.float32, device=x.device)
+        need = ops.siren_fit_workspace_bytes(self.desc, x.shape[0])
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        ops.siren_fit_cycle(self.desc, self.flat, self.grads, self.m, self.v, x, t, w, int(first_acq), self.step_count + 1,
+                            int(n_steps), self.lr, self.betas[0], self.betas[1], self.eps, losses, self._workspace)
+        self.step_count += int(n_steps)
+        return losses[:n_steps]
+
     def release_workspace(self):
         self._workspace = None
 

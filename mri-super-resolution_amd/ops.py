@@ -393,6 +393,46 @@ def siren_fit(desc: SirenDesc, params, grads, m, v, x, target, weight, first_ste
     return workspace
 
 
+def siren_fit_cycle(desc: SirenDesc, params, grads, m, v, x, targets, weights, first_acq: int, first_step: int,
+                    n_steps: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8, losses=None, workspace=None):
+    """``inr_siren_fit_cycle``: ``targets`` (and ``weights``) are [n_acq, n * out_features]; step ``it`` fits acquisition
+    ``(first_acq + it) % n_acq`` (master.py:137-148)."""
+    total, _ = siren_param_layout(desc)
+    for name, t in (("params", params), ("grads", grads), ("m", m), ("v", v)):
+        _chk(t, name)
+        if t.numel() != total:
+            raise ValueError(f"{name} has {t.numel()} floats, layout needs {total}")
+    _chk(x, "x")
+    if x.dim() != 2 or x.shape[1] != desc.in_features:
+        raise ValueError(f"x {tuple(x.shape)} must be [n,{desc.in_features}]")
+    n = x.shape[0]
+    _chk(targets, "targets")
+    if targets.dim() != 2 or targets.shape[1] != n * desc.out_features:
+        raise ValueError("targets must be [n_acq, n*out_features]")
+    n_acq = targets.shape[0]
+    if weights is not None:
+        _chk(weights, "weights")
+        if tuple(weights.shape) != tuple(targets.shape):
+            raise ValueError("weights must have the shape of targets")
+    if not 0 <= int(first_acq) < n_acq:
+        raise ValueError("first_acq out of range")
+    if losses is not None:
+        _chk(losses, "losses")
+        if losses.numel() < n_steps:
+            raise ValueError("losses buffer shorter than n_steps")
+    need = siren_fit_workspace_bytes(desc, n)
+    if workspace is None:
+        workspace = _ws(need, x.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise ValueError("workspace too small")
+    check(lib().inr_siren_fit_cycle(C.byref(desc), params.data_ptr(), grads.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                    x.data_ptr(), targets.data_ptr(), _ptr(weights), int(n_acq), int(first_acq), n,
+                                    int(first_step), int(n_steps), float(lr), float(beta1), float(beta2), float(eps),
+                                    _ptr(losses), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                    _stream()), "inr_siren_fit_cycle")
+    return workspace
+
+
 def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_total: int, loss, workspace=None):
     """Forward + loss + backward of one row shard (no optimizer); see ``inr_siren_loss_grad``."""
     total, _ = siren_param_layout(desc)

@@ -73,10 +73,16 @@ def test_eleven_patients_two_ranks_with_a_gang(golden):
 
 
 def test_full_length_fit_quality_t4(golden):
-    """Tier T4: the full 2,500-step config-1 fit (pat07 slice 11, x2) is judged on PSNR over seeds 0-3, against the
-    reference's own numbers (32.59 / 32.29 / 32.37 / 32.21 dB, mean 32.365, sigma 0.16; reference
-    vs itself at another thread count: +-0.12 dB).  Mean within 0.15 dB, every seed inside the 31.9 - 32.8 band."""
+    """Tier T4: the full 2,500-step config-1 fit (pat07 slice 11, x2) is judged on PSNR over seeds 0-11 against the REAL
+    reference run through the same twelve seeds (tests/golden/cfg1_ref_psnr.npz, written by oracle/gen_golden_t4.py:
+    mean 32.497 dB, sigma 0.168; its seeds 0-3 are BASELINE.md section 2's 32.59 / 32.29 / 32.37 / 32.21).  Full-length
+    fits are chaotic in fp32 (reference vs itself at another thread count: +-0.12 dB), so the comparison is between means:
+    within 0.15 dB (two standard errors of the difference), every seed inside the reference's mean +- 0.6 dB."""
+    ref = golden("cfg1_ref_psnr.npz")
+    assert list(ref["seeds"]) == list(range(12)) and np.allclose(ref["psnr_db"][:4], [32.590, 32.289, 32.370, 32.207], atol=2e-3)
+    ref_mean = float(ref["psnr_db"].mean())
     hr = golden("pat07_slice11.npz")["hr"]
-    vals = [drivers.fit_volume(hr, steps=2500, seed=s, return_recon=False)["psnr_db"] for s in range(4)]
-    assert abs(float(np.mean(vals)) - 32.365) < 0.15, vals
-    assert all(31.9 < v < 32.8 for v in vals), vals
+    vals = [drivers.fit_volume(hr, steps=2500, seed=s, return_recon=False)["psnr_db"] for s in range(12)]
+    print("T4 PSNR per seed:", np.round(vals, 3), "mean %.3f (reference %.3f)" % (np.mean(vals), ref_mean))
+    assert abs(float(np.mean(vals)) - ref_mean) < 0.15, vals
+    assert all(ref_mean - 0.6 < v < ref_mean + 0.6 for v in vals), vals

@@ -368,6 +368,56 @@ def test_trajectory_small_2d_weighted(golden):
     assert O.rel_l2(rec, s["recon180_10"]) < T3
 
 
+def _set_small_kernel(persistent):
+    from mri_super_resolution_amd._lib import lib
+    lib().inr_debug_set(12, 1 if persistent else 0)
+
+
+@pytest.mark.parametrize("hidden,layers,side,feat", [(64, 6, 60, 2), (32, 2, 25, 2), (64, 1, 37, 5), (32, 0, 9, 2)])
+def test_small_net_persistent_kernel_matches_the_two_launch_path(hidden, layers, side, feat):
+    """master.py regime: 3 acquisitions cycling through 13 optimizer steps (targets and weights change every step) inside
+    ONE persistent launch, against the same steps taken one by one through the step kernel + reduce/Adam kernel pair.
+    Same arithmetic, other summation orders: 1e-5 on losses and parameters; ragged row counts (N not a multiple of 64);
+    and the persistent run is bitwise reproducible."""
+    n = side * side
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, feat, generator=g) * 2 - 1).cuda()
+    tg = (torch.rand(3, n, generator=g) * 2 - 1).cuda()
+    wt = torch.rand(3, n, generator=g).cuda()
+    runs = {}
+    for mode in ("two", "multi", "multi2"):
+        torch.manual_seed(5)
+        net = inr.Siren(feat, hidden, layers, 1).cuda()
+        f = inr.SirenFitter(net, lr=3e-4)
+        if mode == "two":
+            _set_small_kernel(False)
+            losses = torch.cat([f.step(x, tg[(1 + i) % 3], 1, wt[(1 + i) % 3]) for i in range(13)])
+            _set_small_kernel(True)
+        else:
+            losses = f.step_cycle(x, tg, 13, wt, first_acq=1)
+        runs[mode] = (host(losses).copy(), host(f.flat).copy(), host(f.grads).copy())
+    assert np.array_equal(bits(runs["multi"][1]), bits(runs["multi2"][1]))
+    assert np.array_equal(bits(runs["multi"][0]), bits(runs["multi2"][0]))
+    assert np.allclose(runs["multi"][0], runs["two"][0], rtol=1e-5)
+    assert O.rel_l2(runs["multi"][1], runs["two"][1]) < 1e-5
+    assert O.rel_l2(runs["multi"][2], runs["two"][2]) < 1e-4          # the 13th step's gradient
+
+
+def test_fit_cycle_on_the_layer_kernels_equals_single_steps(golden):
+    """inr_siren_fit_cycle on a network the small kernels do not take: the acquisition pointer moves, nothing else."""
+    net, x, d = _siren512(golden)
+    n = x.shape[0]
+    g = torch.Generator().manual_seed(3)
+    tg = torch.rand(2, n, generator=g).cuda()
+    f = inr.SirenFitter(net, lr=1e-4)
+    a = host(f.step_cycle(x, tg, 4)).copy()
+    pa = host(f.flat).copy()
+    net2, _, _ = _siren512(golden)
+    f2 = inr.SirenFitter(net2, lr=1e-4)
+    b = np.concatenate([host(f2.step(x, tg[i % 2], 1)) for i in range(4)])
+    assert np.allclose(a, b, rtol=1e-6) and O.rel_l2(pa, host(f2.flat)) < 1e-6
+
+
 def test_fit_is_bitwise_deterministic(golden):
     res = []
     for _ in range(2):
