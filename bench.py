@@ -129,23 +129,47 @@ def cfg2_leg(steps=2500):
             "final_loss": res["final_loss"]}
 
 
-def rams_leg(batch=25, reps=3):
-    """Config 3 (multi-image CNN): RAMS(3,32,3,9,8,12) forward on a synthetic (25,128,128,9) uint16-range batch = the 25
-    random 9-acquisition subsets of one case (multi-image-super-resolution/master.py:43-52) as one batched call."""
+def rams_leg(reps=3):
+    """Config 3 (multi-image CNN): RAMS(3,32,3,9,8,12) forward on synthetic (B,128,128,9) uint16-range stacks: B = 25 = the
+    25 random 9-acquisition subsets of one case (multi-image-super-resolution/master.py:43-52) as one batched call, and
+    B = 1, the reference's own call shape.  The 32 -> 32 convolutions run on the fp16 matrix cores with hi/lo-split operands
+    (activations staged in LDS) for batches, on the f32-input MFMA at batch 1."""
     from mri_super_resolution_amd import rams
     model = rams.RAMS(seed=0)
-    x = torch.from_numpy((np.random.default_rng(0).random((batch, 128, 128, 9)) * 60000).astype(np.float32)).cuda()
-    rams.predict_tensor(model, x)
+    out = {"config": "RAMS(3,32,3,9,8,12) predict_tensor, (B,128,128,9) -> (384,384), random weights", "flop_per_stack": 265.0e9,
+           "peak_tflops_fp32_mfma": PEAK_F32_MFMA_TFLOPS, "peak_tflops_fp32_equivalent_split_fp16": PEAK_F16_MFMA_TFLOPS / 3.0}
+    for batch in (25, 1):
+        x = torch.from_numpy((np.random.default_rng(0).random((batch, 128, 128, 9)) * 60000).astype(np.float32)).cuda()
+        rams.predict_tensor(model, x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rams.predict_tensor(model, x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[f"batch{batch}"] = {"ms_per_stack": dt / batch * 1e3, "stacks_per_s": batch / dt,
+                                "output_voxels_per_s": batch * 384 * 384 / dt, "tflops": 265.0e9 * batch / dt / 1e12}
+    return out
+
+
+def small_net_leg(steps=2000, side=60, n_acq=4):
+    """The master.py regime (a-11): Siren(2,64,6,1) on a 60x60 slice, weighted loss, the acquisition changing every step:
+    microseconds per optimizer step through one inr_siren_fit_cycle call (persistent kernel, 64 steps per launch)."""
+    import mri_super_resolution_amd as inr
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1).cuda()
+    coords = inr.ImageFitting_set([np.zeros((side, side), np.float32)]).coords[0]
+    tg = torch.rand(n_acq, side * side, device="cuda") * 2 - 1
+    wt = torch.rand(n_acq, side * side, device="cuda")
+    f = inr.SirenFitter(net, lr=3e-4)
+    f.step_cycle(coords, tg, 64, wt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(reps):
-        rams.predict_tensor(model, x)
+    f.step_cycle(coords, tg, steps, wt)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    return {"config": f"RAMS(3,32,3,9,8,12) predict_tensor, batch {batch} x (128,128,9) -> (384,384), random weights",
-            "ms_per_stack": dt / batch * 1e3, "stacks_per_s": batch / dt, "output_voxels_per_s": batch * 384 * 384 / dt,
-            "tflops": 265.0e9 * batch / dt / 1e12, "peak_tflops": PEAK_F32_MFMA_TFLOPS,
-            "flop_per_stack": 265.0e9}
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": f"Siren(2,64,6,1), N = {side * side} rows, {n_acq} acquisitions cycling, weighted MSE, Adam 3e-4",
+            "us_per_optimizer_step": dt * 1e6, "train_voxels_per_s": side * side / dt, "steps": steps}
 
 
 def cfg5_leg(steps=4):
@@ -333,7 +357,8 @@ def main():
         gbps = algo_bytes / (avg_ms * 1e-3) / 1e9
         mfma_peak = PEAK_F16_MFMA_TFLOPS / 3.0
         roofline = {"bound": "hbm",
-                    "kernel": "gemm_hp_pkc_kernel / gemm_hp_kernel (HL32 operands by LDS-DMA, 3 x v_mfma_f32_16x16x32_f16 per fp32 product)",
+                    "kernel": "gemm_hp_pkd_kernel / gemm_hp_pkc_kernel / gemm_hp_kernel (persistent, HL32 operands by LDS-DMA, "
+                              "3 x v_mfma_f32_16x16x32_f16 per fp32 product)",
                     "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, **common,
                     "mfma_view": {"achieved_tflops_fp32_equivalent": achieved, "peak_tflops_fp32_equivalent": mfma_peak,
                                   "frac": achieved / mfma_peak,
@@ -408,6 +433,7 @@ def main():
             del rec, net_full
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
+        out["small_net"] = small_net_leg()
         out["cfg2_real_volume"] = cfg2_leg()
         out["cfg5_te_fits"] = cfg5_leg()
         out["hybrid_fit"] = hybrid_fit_leg()

@@ -168,14 +168,19 @@ __global__ void __launch_bounds__(CONV_THREADS, 2) conv3d_c32_mfma_kernel(const 
     if (p.chan_slab && lane < 32) p.chan_slab[((long long)b * p.waves_per_b + wid) * RC + lane] = csum;
 }
 
+#include "rams_h3.inc"
+
 // ---- stem: Conv3D 1 -> 32, 3x3x3 'same' (network.py:119) ----------------------------------------------------
 // x [B][D1][D2][D3], w [27][32], y [B][D1][D2][D3][32]; one thread per (voxel, cout)
 __global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        int B, int D1, int D2, int D3) {
+                                                        int B, int D1, int D2, int D3, unsigned* amax = nullptr) {
     const long long total = (long long)B * D1 * D2 * D3 * RC;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    if (i >= total) {
+        if (amax) r3_wave_amax(0.f, amax);      // (whole waves take part in the shuffle)
+        return;
+    }
     const int c = (int)(i % RC);
     long long v = i / RC;
     const int i3 = (int)(v % D3); v /= D3;
@@ -191,6 +196,7 @@ __global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, c
                     acc = fmaf(x[(((long long)b * D1 + j1) * D2 + j2) * D3 + j3], w[((d1 * 3 + d2) * 3 + d3) * RC + c], acc);
             }
     y[i] = acc;
+    if (amax) r3_wave_amax(acc, amax);
 }
 
 // ---- attention gate: global average pool finish + 1x1 squeeze (ReLU) + 1x1 excite (sigmoid) ---------------------
@@ -231,18 +237,28 @@ __global__ void __launch_bounds__(256) gate_kernel(float* __restrict__ gate, con
 // out = y * gate[b][c] + res   over [B][per_b voxels][C]
 __global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__ out, const float* __restrict__ y,
                                                              const float* __restrict__ gate, const float* __restrict__ res,
-                                                             long long per_b, int C, long long total) {
+                                                             long long per_b, int C, long long total,
+                                                             unsigned* amax = nullptr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const int b = (int)(i / (per_b * C));
-    out[i] = fmaf(y[i], gate[b * C + c], res[i]);
+    float v = 0.f;
+    if (i < total) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / (per_b * C));
+        v = fmaf(y[i], gate[b * C + c], res[i]);
+        out[i] = v;
+    }
+    if (amax) r3_wave_amax(v, amax);
 }
 
 __global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a,
-                                                  const float* __restrict__ b, long long total) {
+                                                  const float* __restrict__ b, long long total, unsigned* amax = nullptr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) out[i] = a[i] + b[i];
+    float v = 0.f;
+    if (i < total) {
+        v = a[i] + b[i];
+        out[i] = v;
+    }
+    if (amax) r3_wave_amax(v, amax);
 }
 
 // (x - MEAN)/STD  (network.py:21-23)
@@ -394,6 +410,78 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 }
 
 int rams_waves_per_b(int B, int ovox);
+int g_rams_force_lds = 0;   // tests: take the LDS-staged kernel whatever the batch size
+int g_rams_h3 = 2;   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
+                     // activations from global; 0 = f32-input MFMA
+
+static int conv3d_h3(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
+                     const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3, int pad,
+                     int cout, int y_cstride, int relu, int waves_per_b, hipStream_t st) {
+    Conv3dH3Params p{};
+    p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
+    p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
+    p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
+    p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
+    p.pad = pad; p.cout = cout; p.y_cstride = y_cstride; p.relu = relu;
+    const int ovox = p.O1 * p.O2 * p.O3;
+    p.tiles_per_b = (ovox + 31) / 32;
+    p.waves_per_b = waves_per_b;
+    p.x_elems_per_b = (long long)D1 * D2 * D3 * RC;
+    ProfScope ps(KC_OTHER, st);
+    const dim3 grid(waves_per_b / (CONV_THREADS / 64), B);
+    if ((long long)p.tiles_per_b >= 6ll * waves_per_b)
+        hipLaunchKernelGGL(conv3d_c32_h3_kernel<2>, grid, dim3(CONV_THREADS), 0, st, p);
+    else
+        hipLaunchKernelGGL(conv3d_c32_h3_kernel<1>, grid, dim3(CONV_THREADS), 0, st, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// patch of the LDS-staged kernel: the most outputs that fit one round of 8 wave tiles (<= 256) whose halo fits the image
+static void r3l_choose_patch(int D3, int O3, int* PO1, int* PO2) {
+    int best = 0, b1 = 1, b2 = 1;
+    for (int a = 1; a <= 16; ++a)
+        for (int c = a; c <= 32; ++c) {
+            if ((a + 2) * (c + 2) * D3 > R3L_MAX_HVOX || a * c * O3 > 256) continue;
+            if (a * c > best) { best = a * c; b1 = a; b2 = c; }
+        }
+    *PO1 = b1;
+    *PO2 = b2;
+}
+static int rams_lds_blocks_per_b(int B, int npatch) {
+    int blocks = 256 / B;
+    if (blocks < 1) blocks = 1;
+    return blocks < npatch ? blocks : npatch;
+}
+
+static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
+                         const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
+                         int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st) {
+    Conv3dLdsParams p{};
+    p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
+    p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
+    p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
+    p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
+    p.pad = pad; p.cout = cout; p.y_cstride = y_cstride; p.relu = relu;
+    r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
+    p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
+    p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
+    const int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
+    if (nslab) *nslab = blocks * 8;
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(conv3d_c32_lds_kernel, dim3(blocks, B), dim3(CONV_THREADS), 0, st, p);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+static inline int rams_conv3d_count(const inr_rams_desc_t* d) { return 2 * d->n_rfab + 1 + 3 * (d->channels / 3) + 1; }
+constexpr int R3_MAX_CONVS = 96;
+struct R3SplitJobs {
+    R3SplitJob j[R3_MAX_CONVS];
+};
+__global__ void __launch_bounds__(512) rams_weight_split_all_kernel(const R3SplitJobs jobs) {
+    rams_weight_split_body(jobs.j[blockIdx.x]);
+}
 
 // ---- building blocks of the training step (utils/training.py:193-209) -------------------------------
 // data gradient of a 'same' 3x3x3 convolution = the same convolution of dy with the kernel flipped along every axis
@@ -568,7 +656,9 @@ size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W) {
     const long long big = (long long)B * (H + 4) * (W + 4) * T * RC;      // largest 5-D activation (padded reduction stage)
     const long long slab = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * (int)T) * RC + 4096;
     const long long small = (long long)B * (H + 2) * (W + 2) * T * 4 + (long long)B * H * W * d->scale * d->scale * 2;
-    return (size_t)(5 * big + slab + small + 8192);
+    // split-fp16 inference: hi/lo planes of every 32 -> 32 kernel + scale slots
+    const long long h3 = (long long)rams_conv3d_count(d) * (R3_LAYER_HALVES / 2) + 1024;
+    return (size_t)(5 * big + slab + small + 8192 + h3);
 }
 
 int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float* x, float* out, int B, int H, int W,
@@ -590,8 +680,58 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     float* g2 = g1 + (long long)B * (H + 2) * (W + 2) * T;
     float* upo = g2 + (long long)B * (H + 2) * (W + 2) * T;   // [B][H][W][S2]
     float* glo = upo + (long long)B * H * W * S2;
+    // split-fp16 state behind everything else: [slots: 1024 x u32][planes of conv 0][planes of conv 1]...
+    // LDS-staged kernel when a block has a few patches to pipeline (batch >= 2 at 128 x 128); the reference's own call
+    // shape, batch 1, keeps the f32-input kernels throughout: 2.4 patches per block leave nothing to overlap the staging
+    // with (measured 4.5 ms per stack against 3.9)
+    bool h3 = g_rams_h3 != 0;
+    if (g_rams_h3 == 2 && !g_rams_force_lds) {
+        int po1, po2;
+        r3l_choose_patch(T, T, &po1, &po2);
+        const long long patches = (long long)B * ((H + 2 + po1 - 1) / po1) * ((W + 2 + po2 - 1) / po2);
+        if (patches < 4 * 256) h3 = false;
+    }
+    const int n_conv = rams_conv3d_count(d);
+    INR_REQUIRE(n_conv <= R3_MAX_CONVS, INR_E_INVALID, "rams: too many 3-D convolutions (%d)", n_conv);
+    unsigned* slots = reinterpret_cast<unsigned*>(ws + 5 * big + slab_floats + (long long)B * H * W * T +
+                                                  3 * (long long)B * (H + 2) * (W + 2) * T + 2 * (long long)B * H * W * S2 + 64);
+    slots = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(slots) + 255) & ~(uintptr_t)255);
+    _Float16* planes = reinterpret_cast<_Float16*>(slots + 1024);
+    int conv_no = 0, next_slot = n_conv;      // slots [0, n_conv): max|w| per convolution; the rest: max|x| per tensor
+    auto new_slot = [&]() { return slots + next_slot++; };
+    if (h3) {
+        INR_HIP(hipMemsetAsync(slots, 0, 1024 * sizeof(unsigned), st));
+        // the 3-D kernels in consumption order (same walk as below)
+        R3SplitJobs jobs{};
+        Cursor w{params};
+        int k = 0;
+        auto conv = [&]() { jobs.j[k] = {w.take(CONV_W_FLOATS), planes + (long long)k * R3_LAYER_HALVES, slots + k}; ++k; w.take(RC); };
+        auto skip_gate = [&](int C, int Cr2) { w.take((long long)C * Cr2); w.take(Cr2); w.take((long long)Cr2 * C); w.take(C); };
+        w.take(27 * RC); w.take(RC);
+        for (int i = 0; i < d->n_rfab; ++i) { conv(); conv(); skip_gate(RC, Cr); }
+        conv();
+        for (int i = 0; i < T / 3; ++i) { conv(); conv(); skip_gate(RC, Cr); conv(); }
+        conv();
+        hipLaunchKernelGGL(rams_weight_split_all_kernel, dim3(n_conv), dim3(512), 0, st, jobs);
+        INR_LAUNCH_CHECK();
+    }
+    // one 3-D convolution (either arithmetic); xs = slot of max|x|, ys = slot that receives max|y| (nullable)
+    int last_nslab = 0;      // channel-sum slabs the last convolution wrote per batch element
+    auto conv3d = [&](const float* xin, float* yout, const float* w, const float* bias, float* chan, const unsigned* xs,
+                      unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb) -> int {
+        const int k = conv_no++;
+        last_nslab = wpb;
+        if (h3 && g_rams_h3 == 2 && D3 * 9 <= R3L_MAX_HVOX)  // (a 3 x 3 halo of one output column must fit the image)
+            return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
+                                 pad, cout, cstride, relu, &last_nslab, st);
+        if (h3)
+            return conv3d_h3(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3, pad,
+                             cout, cstride, relu, wpb, st);
+        return conv3d_mfma(xin, yout, w, bias, chan, B, D1, D2, D3, pad, cout, cstride, relu, wpb, st);
+    };
     Cursor c{params};
 
+    unsigned* io_slot = nullptr;   // slot of max|.| of the tensor the next convolution reads
     auto rfab = [&](float* io, int D1, int D2, int D3) -> int {   // io updated in place: io = gate*conv2(relu(conv1(io))) + io
         const float* w1 = c.take(CONV_W_FLOATS); const float* b1 = c.take(RC);
         const float* w2 = c.take(CONV_W_FLOATS); const float* b2 = c.take(RC);
@@ -599,14 +739,16 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         const float* wex = c.take((long long)Cr * RC); const float* bex = c.take(RC);
         const int ovox = D1 * D2 * D3;
         const int wpb = rams_waves_per_b(B, ovox);
-        if (int rc = conv3d_mfma(io, bufB, w1, b1, nullptr, B, D1, D2, D3, 1, RC, RC, 1, wpb, st)) return rc;
-        if (int rc = conv3d_mfma(bufB, bufC, w2, b2, slab, B, D1, D2, D3, 1, RC, RC, 0, wpb, st)) return rc;
-        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, wpb, 1.0f / (float)ovox, wsq, bsq, wex, bex,
-                           RC, Cr);
+        unsigned* mid = h3 ? new_slot() : nullptr;
+        if (int rc = conv3d(io, bufB, w1, b1, nullptr, io_slot, mid, D1, D2, D3, 1, RC, RC, 1, wpb)) return rc;
+        if (int rc = conv3d(bufB, bufC, w2, b2, slab, mid, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
+        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, last_nslab, 1.0f / (float)ovox, wsq, bsq, wex,
+                           bex, RC, Cr);
         INR_LAUNCH_CHECK();
         const long long total = (long long)B * ovox * RC;
+        io_slot = h3 ? new_slot() : nullptr;
         hipLaunchKernelGGL(scale_residual_kernel, dim3(nblk(total)), dim3(256), 0, st, io, bufC, gate, io, (long long)ovox,
-                           RC, total);
+                           RC, total, io_slot);
         INR_LAUNCH_CHECK();
         return 0;
     };
@@ -622,8 +764,9 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     int D1 = H + 2, D2 = W + 2, D3 = T;
     {   // stem (network.py:119)
         const float* w = c.take(27 * RC); const float* b = c.take(RC);
+        io_slot = h3 ? new_slot() : nullptr;
         hipLaunchKernelGGL(conv3d_c1_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * RC)), dim3(256), 0, st, bufA, xpad, w, b,
-                           B, D1, D2, D3);
+                           B, D1, D2, D3, io_slot);
         INR_LAUNCH_CHECK();
     }
     INR_HIP(hipMemcpyAsync(bufR, bufA, (size_t)B * D1 * D2 * D3 * RC * 4, hipMemcpyDeviceToDevice, st));
@@ -632,26 +775,29 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     {   // trunk close + long skip (network.py:127-129)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
         const int wpb = rams_waves_per_b(B, D1 * D2 * D3);
-        if (int rc = conv3d_mfma(bufA, bufB, w, b, nullptr, B, D1, D2, D3, 1, RC, RC, 0, wpb, st)) return rc;
+        if (int rc = conv3d(bufA, bufB, w, b, nullptr, io_slot, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
         const long long total = (long long)B * D1 * D2 * D3 * RC;
-        hipLaunchKernelGGL(add_kernel, dim3(nblk(total)), dim3(256), 0, st, bufA, bufB, bufR, total);
+        io_slot = h3 ? new_slot() : nullptr;
+        hipLaunchKernelGGL(add_kernel, dim3(nblk(total)), dim3(256), 0, st, bufA, bufB, bufR, total, io_slot);
         INR_LAUNCH_CHECK();
     }
     for (int i = 0; i < T / 3; ++i) {   // temporal reduction (network.py:132-136)
         hipLaunchKernelGGL(reflect_pad_kernel, dim3(nblk((long long)B * (D1 + 2) * (D2 + 2) * D3 * RC)), dim3(256), 0, st, bufP,
                            bufA, B, D1, D2, D3 * RC);
         INR_LAUNCH_CHECK();
-        if (int rc = rfab(bufP, D1 + 2, D2 + 2, D3)) return rc;
+        if (int rc = rfab(bufP, D1 + 2, D2 + 2, D3)) return rc;      // (reflect padding copies values: max|.| carries over)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
         const int wpb = rams_waves_per_b(B, D1 * D2 * (D3 - 2));
-        if (int rc = conv3d_mfma(bufP, bufA, w, b, nullptr, B, D1 + 2, D2 + 2, D3, 0, RC, RC, 1, wpb, st)) return rc;
+        unsigned* out_slot = h3 ? new_slot() : nullptr;
+        if (int rc = conv3d(bufP, bufA, w, b, nullptr, io_slot, out_slot, D1 + 2, D2 + 2, D3, 0, RC, RC, 1, wpb)) return rc;
+        io_slot = out_slot;
         D3 -= 2;
     }
     {   // up-scaling head: Conv3D 32 -> scale^2, valid; keep T index 0 (network.py:139-140)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
         INR_REQUIRE(D3 == 3, INR_E_INVALID, "rams: temporal depth before the head must be 3 (got %d)", D3);
         const int wpb = rams_waves_per_b(B, (D1 - 2) * (D2 - 2));
-        if (int rc = conv3d_mfma(bufA, upo, w, b, nullptr, B, D1, D2, D3, 0, S2, S2, 0, wpb, st)) return rc;
+        if (int rc = conv3d(bufA, upo, w, b, nullptr, io_slot, nullptr, D1, D2, D3, 0, S2, S2, 0, wpb)) return rc;
     }
     {   // global residual path: RTAB on the padded normalised input + valid conv (network.py:145-148)
         const float* w1 = c.take(9LL * T * T); const float* b1 = c.take(T);
