@@ -166,7 +166,7 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
                    int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
 extern int g_force_generic;
 extern int g_small_rows;
-extern int g_rams_h3, g_rams_force_lds;
+extern int g_rams_h3, g_rams_force_lds, g_rams_lds_waves;
 int g_small_multi = 1;   // small networks: 1 = persistent multi-step kernel (default), 0 = two launches per step
 extern int g_mfma16;
 extern int g_h3;
@@ -1291,6 +1291,7 @@ int inr_debug_set(int key, int value) {
     if (key == 12) { g_small_multi = value; return 0; }
     if (key == 13) { g_small_rows = value; return 0; }
     if (key == 14) { g_rams_h3 = value & 3; g_rams_force_lds = (value >> 2) & 1; return 0; }
+    if (key == 15) { g_rams_lds_waves = value == 8 ? 8 : 4; return 0; }
     if (key == 11) { g_hp_stagger = value; return 0; }
     if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...
     if (key == 9) { g_stamp_nth = value; return 0; }     // ... and only the n-th one since this call (counts down)

@@ -250,6 +250,30 @@ __global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__
     if (amax) r3_wave_amax(v, amax);
 }
 
+// the same for C = 32 with 16-byte accesses; one batch element per blockIdx.y (no 64-bit divisions)
+__global__ void __launch_bounds__(256) scale_residual_c32_kernel(float* __restrict__ out, const float* __restrict__ y,
+                                                                 const float* __restrict__ gate, const float* __restrict__ res,
+                                                                 long long per_b4 /* float4 per batch element */,
+                                                                 unsigned* amax) {
+    const int b = blockIdx.y;
+    const f32x4* y4 = reinterpret_cast<const f32x4*>(y) + (long long)b * per_b4;
+    const f32x4* r4 = reinterpret_cast<const f32x4*>(res) + (long long)b * per_b4;
+    f32x4* o4 = reinterpret_cast<f32x4*>(out) + (long long)b * per_b4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gate + b * RC + 4 * (threadIdx.x & 7));     // 256 % 8 == 0: fixed per thread
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_b4; i += (long long)gridDim.x * 256) {
+        const f32x4 yv = y4[i], rv = r4[i];
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = fmaf(yv[q], g[q], rv[q]);
+            m = fmaxf(m, fabsf(v[q]));
+        }
+        o4[i] = v;
+    }
+    if (amax) r3_wave_amax(m, amax);
+}
+
 __global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a,
                                                   const float* __restrict__ b, long long total, unsigned* amax = nullptr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -283,6 +307,67 @@ __global__ void __launch_bounds__(256) reflect_pad_kernel(float* __restrict__ ou
     i1 = i1 < 0 ? -i1 : (i1 >= D1 ? 2 * D1 - 2 - i1 : i1);
     i2 = i2 < 0 ? -i2 : (i2 >= D2 ? 2 * D2 - 2 - i2 : i2);
     out[i] = x[(((long long)b * D1 + i1) * D2 + i2) * inner + k];
+}
+
+// 16-byte versions for the 5-D trunk tensors (inner = T * 32 floats): one (b, o1, o2) row per block column
+__global__ void __launch_bounds__(256) reflect_pad_v4_kernel(float* __restrict__ out, const float* __restrict__ x, int D1,
+                                                             int D2, int inner4) {
+    const int o2 = blockIdx.x % (D2 + 2), o1 = blockIdx.x / (D2 + 2), b = blockIdx.y;
+    int i1 = o1 - 1, i2 = o2 - 1;
+    i1 = i1 < 0 ? -i1 : (i1 >= D1 ? 2 * D1 - 2 - i1 : i1);
+    i2 = i2 < 0 ? -i2 : (i2 >= D2 ? 2 * D2 - 2 - i2 : i2);
+    const f32x4* src = reinterpret_cast<const f32x4*>(x) + (((long long)b * D1 + i1) * D2 + i2) * inner4;
+    f32x4* dst = reinterpret_cast<f32x4*>(out) + (((long long)b * (D1 + 2) + o1) * (D2 + 2) + o2) * inner4;
+    for (int k = threadIdx.x; k < inner4; k += 256) dst[k] = src[k];
+}
+
+__global__ void __launch_bounds__(256) add_v4_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                     const float* __restrict__ b, long long total4, unsigned* amax) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const f32x4 av = reinterpret_cast<const f32x4*>(a)[i], bv = reinterpret_cast<const f32x4*>(b)[i];
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = av[q] + bv[q];
+            m = fmaxf(m, fabsf(v[q]));
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+    if (amax) r3_wave_amax(m, amax);
+}
+
+// stem with four output channels per thread (one 16-byte store; the 27 inputs are read once per four outputs)
+__global__ void __launch_bounds__(256) conv3d_c1_v4_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int B, int D1, int D2, int D3, unsigned* amax) {
+    const long long total4 = (long long)B * D1 * D2 * D3 * (RC / 4);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (i < total4) {
+        const int c4 = (int)(i % (RC / 4));
+        long long v = i / (RC / 4);
+        const int i3 = (int)(v % D3); v /= D3;
+        const int i2 = (int)(v % D2); v /= D2;
+        const int i1 = (int)(v % D1);
+        const int b = (int)(v / D1);
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+        for (int d1 = 0; d1 < 3; ++d1)
+            for (int d2 = 0; d2 < 3; ++d2)
+                for (int d3 = 0; d3 < 3; ++d3) {
+                    const int j1 = i1 + d1 - 1, j2 = i2 + d2 - 1, j3 = i3 + d3 - 1;
+                    if ((unsigned)j1 < (unsigned)D1 && (unsigned)j2 < (unsigned)D2 && (unsigned)j3 < (unsigned)D3) {
+                        const float xv = x[(((long long)b * D1 + j1) * D2 + j2) * D3 + j3];
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + ((d1 * 3 + d2) * 3 + d3) * RC + 4 * c4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[q] = fmaf(xv, wv[q], acc[q]);
+                    }
+                }
+        reinterpret_cast<f32x4*>(y)[i] = acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[q]));
+    }
+    if (amax) r3_wave_amax(m, amax);
 }
 
 // ---- 2-D branch (RTAB on the 9 normalised inputs, network.py:145-148): direct kernels ----------------------------
@@ -410,6 +495,8 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 }
 
 int rams_waves_per_b(int B, int ovox);
+int g_rams_lds_waves = 8;   // LDS-staged kernel: 8 waves x 1 tile per block (default: 33.2 ms per 25 stacks) or 4 waves x 2 tiles
+                            // sharing the weight fragments (34.6 ms: one wave per SIMD hides less latency than it saves bytes)
 int g_rams_force_lds = 0;   // tests: take the LDS-staged kernel whatever the batch size
 int g_rams_h3 = 2;   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
                      // activations from global; 0 = f32-input MFMA
@@ -467,9 +554,14 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
     p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
     p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
     const int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
-    if (nslab) *nslab = blocks * 8;
     ProfScope ps(KC_OTHER, st);
-    hipLaunchKernelGGL(conv3d_c32_lds_kernel, dim3(blocks, B), dim3(CONV_THREADS), 0, st, p);
+    if (g_rams_lds_waves == 8) {
+        if (nslab) *nslab = blocks * 8;
+        hipLaunchKernelGGL((conv3d_c32_lds_kernel<8, 1>), dim3(blocks, B), dim3(512), 0, st, p);
+    } else {
+        if (nslab) *nslab = blocks * 4;
+        hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2>), dim3(blocks, B), dim3(256), 0, st, p);
+    }
     INR_LAUNCH_CHECK();
     return 0;
 }
@@ -747,8 +839,14 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         INR_LAUNCH_CHECK();
         const long long total = (long long)B * ovox * RC;
         io_slot = h3 ? new_slot() : nullptr;
-        hipLaunchKernelGGL(scale_residual_kernel, dim3(nblk(total)), dim3(256), 0, st, io, bufC, gate, io, (long long)ovox,
-                           RC, total, io_slot);
+        {
+            const long long per_b4 = (long long)ovox * RC / 4;
+            long long gx = (per_b4 + 255) / 256;
+            const long long cap = (8 * 256 + B - 1) / B;          // ~8 blocks per CU over the whole batch
+            if (gx > cap) gx = cap;
+            hipLaunchKernelGGL(scale_residual_c32_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, io, bufC, gate, io, per_b4,
+                               io_slot);
+        }
         INR_LAUNCH_CHECK();
         return 0;
     };
@@ -765,8 +863,8 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     {   // stem (network.py:119)
         const float* w = c.take(27 * RC); const float* b = c.take(RC);
         io_slot = h3 ? new_slot() : nullptr;
-        hipLaunchKernelGGL(conv3d_c1_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * RC)), dim3(256), 0, st, bufA, xpad, w, b,
-                           B, D1, D2, D3, io_slot);
+        hipLaunchKernelGGL(conv3d_c1_v4_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * (RC / 4))), dim3(256), 0, st, bufA, xpad,
+                           w, b, B, D1, D2, D3, io_slot);
         INR_LAUNCH_CHECK();
     }
     INR_HIP(hipMemcpyAsync(bufR, bufA, (size_t)B * D1 * D2 * D3 * RC * 4, hipMemcpyDeviceToDevice, st));
@@ -778,12 +876,11 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         if (int rc = conv3d(bufA, bufB, w, b, nullptr, io_slot, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
         const long long total = (long long)B * D1 * D2 * D3 * RC;
         io_slot = h3 ? new_slot() : nullptr;
-        hipLaunchKernelGGL(add_kernel, dim3(nblk(total)), dim3(256), 0, st, bufA, bufB, bufR, total, io_slot);
+        hipLaunchKernelGGL(add_v4_kernel, dim3(2048), dim3(256), 0, st, bufA, bufB, bufR, total / 4, io_slot);
         INR_LAUNCH_CHECK();
     }
     for (int i = 0; i < T / 3; ++i) {   // temporal reduction (network.py:132-136)
-        hipLaunchKernelGGL(reflect_pad_kernel, dim3(nblk((long long)B * (D1 + 2) * (D2 + 2) * D3 * RC)), dim3(256), 0, st, bufP,
-                           bufA, B, D1, D2, D3 * RC);
+        hipLaunchKernelGGL(reflect_pad_v4_kernel, dim3((D1 + 2) * (D2 + 2), B), dim3(256), 0, st, bufP, bufA, D1, D2, D3 * RC / 4);
         INR_LAUNCH_CHECK();
         if (int rc = rfab(bufP, D1 + 2, D2 + 2, D3)) return rc;      // (reflect padding copies values: max|.| carries over)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);

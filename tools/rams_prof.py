@@ -1,7 +1,11 @@
+"""RAMS forward under the profiler: `rocprofv3 --kernel-trace --stats -- python3 tools/rams_prof.py [batch]` (default model
+RAMS(3,32,3,9,8,12), (B,128,128,9) stacks; one warm call + three profiled-alike calls)."""
 import sys, os, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mri_super_resolution_amd import rams
-model = rams.RAMS(seed=0, N=2)
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+model = rams.RAMS(seed=0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 xt = torch.from_numpy((np.random.default_rng(0).random((B, 128, 128, 9)) * 60000).astype(np.float32)).cuda()
-model(xt); model(xt); torch.cuda.synchronize()
+for _ in range(4):
+    model(xt)
+torch.cuda.synchronize()
