@@ -1053,7 +1053,8 @@ int inr_hybrid_fit(double* params, int* status, int* nfev, double* cost, const d
                    void* stream) {
     if (n_voxels == 0) return 0;
     INR_REQUIRE(params && status && nfev && cost && signals, INR_E_INVALID, "inr_hybrid_fit: null pointer");
-    INR_REQUIRE(n_voxels > 0 && n_voxels <= ((int64_t)1 << 36), INR_E_INVALID, "inr_hybrid_fit: bad voxel count %lld",
+    // (one 8-lane group per voxel, grid dimension is 32-bit: 2^31 - 1 blocks of 8 voxels)
+    INR_REQUIRE(n_voxels > 0 && n_voxels <= ((int64_t)1 << 33), INR_E_INVALID, "inr_hybrid_fit: bad voxel count %lld",
                 (long long)n_voxels);
     return launch_hybrid_fit(params, status, nfev, cost, signals, n_voxels, (hipStream_t)stream);
 }
@@ -1080,6 +1081,8 @@ static int conv3d_dims_ok(int B, int D1, int D2, int D3, int pad) {
                 "conv3d: bad shape (B=%d D=%dx%dx%d pad=%d)", B, D1, D2, D3, pad);
     INR_REQUIRE(D1 + 2 * pad > 2 && D2 + 2 * pad > 2 && D3 + 2 * pad > 2, INR_E_INVALID, "conv3d: volume smaller than the kernel");
     INR_REQUIRE((long long)B * D1 * D2 * D3 * 32 * 4 < (1ll << 40), INR_E_INVALID, "conv3d: volume too large");
+    // the kernels address one image through a 32-bit buffer window
+    INR_REQUIRE((long long)D1 * D2 * D3 * 32 * 4 < (1ll << 31), INR_E_INVALID, "conv3d: one image must stay below 2 GiB");
     return 0;
 }
 

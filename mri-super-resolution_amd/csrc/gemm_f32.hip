@@ -1055,6 +1055,12 @@ int param_grad_splits(int64_t n, int in_f, int out_f) {
     long long s = want < max_by_work ? want : max_by_work;
     if (s < 1) s = 1;
     if (s > 512) s = 512;
+    // every split's row range must stay inside a 2 GiB operand window (wide layers at millions of rows)
+    const long long widest = out_f > in_f ? out_f : in_f;
+    const long long rows_max = ((1ll << 31) - 1) / (widest * 4) / BK * BK;
+    const long long need = rows_max > 0 ? (n + rows_max - 1) / rows_max : (1ll << 30);
+    if (need > s) s = need;
+    if (s > (1 << 20)) s = 1 << 20;     // (the caller's range check rejects what still does not fit)
     return (int)s;
 }
 
@@ -1075,6 +1081,10 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
     p.splits = splits;
     const long long ksteps = (n + BK - 1) / BK;
     p.k_per_split = (int)((ksteps + splits - 1) / splits) * BK;
+    // a block reads its row range through a 32-bit buffer window: the range must stay below 2 GiB in either operand
+    INR_REQUIRE((long long)p.k_per_split * (out_f > in_f ? out_f : in_f) * 4 < (1ll << 31), INR_E_INVALID,
+                "param-grad: %lld rows x %d columns per split do not fit a 2 GiB operand window (more splits needed)",
+                (long long)p.k_per_split, out_f > in_f ? out_f : in_f);
     p.slab_stride = (long long)out_f * in_f;
     p.a_elems = (long long)n * out_f; p.b_elems = (long long)n * in_f; p.c_elems = (long long)splits * out_f * in_f;
     const bool vec = vec_ok(dz, x, out_f, in_f, out_f, in_f);

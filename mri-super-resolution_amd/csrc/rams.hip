@@ -201,23 +201,34 @@ __global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, c
 
 // ---- attention gate: global average pool finish + 1x1 squeeze (ReLU) + 1x1 excite (sigmoid) ---------------------
 // slab [B][nslab][C] partial channel sums -> gate [B][C].  One block per batch element.
-__global__ void __launch_bounds__(256) gate_kernel(float* __restrict__ gate, const float* __restrict__ slab, int nslab,
-                                                   float inv_count, const float* __restrict__ wsq /*[C][Cr]*/,
-                                                   const float* __restrict__ bsq, const float* __restrict__ wex /*[Cr][C]*/,
-                                                   const float* __restrict__ bex, int C, int Cr) {
-    __shared__ float part[256];
+__global__ void __launch_bounds__(1024) gate_kernel(float* __restrict__ gate, const float* __restrict__ slab, int nslab,
+                                                    float inv_count, const float* __restrict__ wsq /*[C][Cr]*/,
+                                                    const float* __restrict__ bsq, const float* __restrict__ wex /*[Cr][C]*/,
+                                                    const float* __restrict__ bex, int C, int Cr) {
+    // 32 phases x 32 channels; a phase sums every 32nd slab with four independent accumulators (a batch-1 call has 2,048
+    // slabs and ONE block: a serial chain of dependent loads was 59 us), phases combined in fixed order
+    __shared__ float part[1024];
     __shared__ float mean[32];
     __shared__ float sq[8];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int c = t % 32, ph = t / 32;  // 8 phases
-    float acc = 0.f;
-    if (c < C)
-        for (int s = ph; s < nslab; s += 8) acc += slab[((long long)b * nslab + s) * C + c];
-    part[t] = acc;
+    const int c = t % 32, ph = t / 32;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+        const float* base = slab + (long long)b * nslab * C + c;
+        int s = ph;
+        for (; s + 96 < nslab; s += 128) {
+            a0 += base[(long long)s * C];
+            a1 += base[(long long)(s + 32) * C];
+            a2 += base[(long long)(s + 64) * C];
+            a3 += base[(long long)(s + 96) * C];
+        }
+        for (; s < nslab; s += 32) a0 += base[(long long)s * C];
+    }
+    part[t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (t < C) {
         float m = 0.f;
-        for (int k = 0; k < 8; ++k) m += part[k * 32 + t];
+        for (int k = 0; k < 32; ++k) m += part[k * 32 + t];
         mean[t] = m * inv_count;
     }
     __syncthreads();
@@ -497,7 +508,7 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 int rams_waves_per_b(int B, int ovox);
 int g_rams_lds_waves = 8;   // LDS-staged kernel: 8 waves x 1 tile per block (default: 33.2 ms per 25 stacks) or 4 waves x 2 tiles
                             // sharing the weight fragments (34.6 ms: one wave per SIMD hides less latency than it saves bytes)
-int g_rams_force_lds = 0;   // tests: take the LDS-staged kernel whatever the batch size
+int g_rams_force_lds = 0;   // (kept for the debug key's bit 2; the LDS-staged kernel is the default at every batch size now)
 int g_rams_h3 = 2;   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
                      // activations from global; 0 = f32-input MFMA
 
@@ -773,16 +784,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     float* upo = g2 + (long long)B * (H + 2) * (W + 2) * T;   // [B][H][W][S2]
     float* glo = upo + (long long)B * H * W * S2;
     // split-fp16 state behind everything else: [slots: 1024 x u32][planes of conv 0][planes of conv 1]...
-    // LDS-staged kernel when a block has a few patches to pipeline (batch >= 2 at 128 x 128); the reference's own call
-    // shape, batch 1, keeps the f32-input kernels throughout: 2.4 patches per block leave nothing to overlap the staging
-    // with (measured 4.5 ms per stack against 3.9)
-    bool h3 = g_rams_h3 != 0;
-    if (g_rams_h3 == 2 && !g_rams_force_lds) {
-        int po1, po2;
-        r3l_choose_patch(T, T, &po1, &po2);
-        const long long patches = (long long)B * ((H + 2 + po1 - 1) / po1) * ((W + 2 + po2 - 1) / po2);
-        if (patches < 4 * 256) h3 = false;
-    }
+    const bool h3 = g_rams_h3 != 0;
     const int n_conv = rams_conv3d_count(d);
     INR_REQUIRE(n_conv <= R3_MAX_CONVS, INR_E_INVALID, "rams: too many 3-D convolutions (%d)", n_conv);
     unsigned* slots = reinterpret_cast<unsigned*>(ws + 5 * big + slab_floats + (long long)B * H * W * T +
@@ -834,7 +836,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         unsigned* mid = h3 ? new_slot() : nullptr;
         if (int rc = conv3d(io, bufB, w1, b1, nullptr, io_slot, mid, D1, D2, D3, 1, RC, RC, 1, wpb)) return rc;
         if (int rc = conv3d(bufB, bufC, w2, b2, slab, mid, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
-        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, last_nslab, 1.0f / (float)ovox, wsq, bsq, wex,
+        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(1024), 0, st, gate, slab, last_nslab, 1.0f / (float)ovox, wsq, bsq, wex,
                            bex, RC, Cr);
         INR_LAUNCH_CHECK();
         const long long total = (long long)B * ovox * RC;
@@ -911,7 +913,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         const int nb2 = 64;
         hipLaunchKernelGGL(chan_partial_kernel, dim3(nb2, B), dim3(256), 0, st, slab, g2, (long long)P1 * P2, T, nb2);
         INR_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(256), 0, st, gate, slab, nb2, 1.0f / (float)(P1 * P2), wsq, bsq, wex, bex,
+        hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(1024), 0, st, gate, slab, nb2, 1.0f / (float)(P1 * P2), wsq, bsq, wex, bex,
                            T, Tr);
         INR_LAUNCH_CHECK();
         hipLaunchKernelGGL(scale_residual_kernel, dim3(nblk(tot)), dim3(256), 0, st, g1, g2, gate, xpad, (long long)P1 * P2, T,
