@@ -1164,8 +1164,12 @@ static int hp_check_grid(const HpParams& p) {
 }
 
 // act (HL32 [n][out_f]) = sin(omega (x W^T + b)); dact (fp32, nullable) = omega cos(.)
+// may the last sine layer of a fit step stash z only (HPE_Z)?  (deferred-epilogue kernel shapes; debug key 16)
+int g_hp_zhead = 1;
+bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
+
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
-                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream) {
+                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only) {
     HpParams p{};
     p.A = x_hl; p.B = W_hl;
     p.M = (int)n; p.N = out_f; p.K = in_f;
@@ -1181,7 +1185,11 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
     p.stamps = hp_stamp_target(KC_GEMM_FWD);
     ProfScope ps(KC_GEMM_FWD, stream);
     const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-    if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
+    if (z_only) {   // (caller checked hp_z_stash_ok): z + b as fp32 into `dact`, nothing else
+        INR_REQUIRE(dact && hp_z_stash_ok(in_f), INR_E_INVALID, "hp_sine_forward: z-only stash needs the deferred-epilogue kernel");
+        if (in_f == 512) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 16>), pgrid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 8>), pgrid, block, 0, stream, p);
+    } else if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
         if (in_f == 512) {
             if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 16>), pgrid, block, 0, stream, p);
             else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 16>), pgrid, block, 0, stream, p);
@@ -1301,14 +1309,20 @@ int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bia
 // slab_b / slab_w: [blocks][hidden], part_loss / part_g: [blocks], blocks = ceil(n / 256)
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
-                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream) {
+                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z, float omega) {
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
     const int rpb = 256;
     const dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
     ProfScope ps(KC_OTHER, stream);
 #define HP_HEAD_STEP(CPL)                                                                                                   \
-    hipLaunchKernelGGL(hp_head_step_kernel<CPL>, grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss, part_g, a_hl, dact, \
-                       W, bias, t, wgt, n, inv, amax_out, so, rpb)
+    do {                                                                                                                    \
+        if (from_z)                                                                                                         \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,   \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega);                        \
+        else                                                                                                                \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,  \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega);                        \
+    } while (0)
     switch (hidden) {
         case 128: HP_HEAD_STEP(2); break;
         case 256: HP_HEAD_STEP(4); break;
