@@ -132,6 +132,35 @@ def cfg2_leg(steps=2500):
             "final_loss": res["final_loss"]}
 
 
+def cfg4_leg(steps=2500):
+    """Config 4 on ONE GPU: all 11 patients' mean-b0 volumes (committed fixtures, z = 24 / 28 / 34) fitted one after the
+    other through `drivers.run_volumes` (2,500 steps + x4 re-sampling + PSNR / SSIM each): the single-GPU time the 8-GPU
+    plan (dist.plan_fits: three 34-slice volumes row-sharded over 3 + 3 + 2 ranks, the rest one per rank) divides."""
+    p7 = os.path.join(ROOT, "tests", "golden", "pat07_volume.npz")
+    rest = os.path.join(ROOT, "tests", "golden", "patients_mean_b0.npz")
+    if not (os.path.exists(p7) and os.path.exists(rest)):
+        return None
+    from mri_super_resolution_amd import dist as inr_dist
+    from mri_super_resolution_amd import drivers
+    z = np.load(rest)
+    names = sorted(list(z.keys()) + ["pat07"])
+    vols = [np.load(p7)["vol"] if n == "pat07" else z[n] for n in names]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    recs = drivers.run_volumes(vols, steps=steps, seed=0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    costs = [float(64 * 64 * v.shape[2]) * steps for v in vols]
+    plan8 = inr_dist.plan_fits(costs, 8)
+    return {"config": f"11 patients (z = {sorted(set(v.shape[2] for v in vols))}), LR 64x64xz -> x4, {steps} steps each, one GPU",
+            "seconds_total": dt, "coordinate_steps_per_s": sum(costs) / sum(r["t_fit"] for r in recs),
+            "psnr_db": {n: round(r["psnr_db"], 3) for n, r in zip(names, recs)},
+            "ssim_mean": {n: round(r["ssim_mean"], 4) for n, r in zip(names, recs)},
+            "psnr_db_mean": float(np.mean([r["psnr_db"] for r in recs])),
+            "modelled_speedup_8_gpus": sum(costs) / plan8["makespan"], "modelled_note": "dist.plan_fits cost model, 3 % "
+            "all-reduce overhead assumed for row-sharded fits; NOT measured (no 8-GPU node in this round)"}
+
+
 def rams_leg(reps=3):
     """Config 3 (multi-image CNN): RAMS(3,32,3,9,8,12) forward on synthetic (B,128,128,9) uint16-range stacks: B = 25 = the
     25 random 9-acquisition subsets of one case (multi-image-super-resolution/master.py:43-52) as one batched call, and
@@ -244,6 +273,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--no-full-fit", action="store_true", help="skip the complete 2,500-step fit (about half a minute)")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the 11-patient leg (about a minute)")
     ap.add_argument("--fp32-mfma", action="store_true",
                     help="A/B: run the GEMMs on the f32-input MFMA kernels instead of the split-fp16 ones")
     args = ap.parse_args()
@@ -441,6 +471,8 @@ def main():
         out["rams"] = rams_leg()
         out["small_net"] = small_net_leg()
         out["cfg2_real_volume"] = cfg2_leg()
+        if not args.no_cfg4:
+            out["cfg4_eleven_patients"] = cfg4_leg()
         out["cfg5_te_fits"] = cfg5_leg()
         out["hybrid_fit"] = hybrid_fit_leg()
     if not args.no_cpu_baseline and world == 1:

@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, c
     const long long total = (long long)B * D1 * D2 * D3 * RC;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) {
-        if (amax) r3_wave_amax(0.f, amax);      // (whole waves take part in the shuffle)
+        if (amax) r3_block_amax(0.f, amax);     // (the whole block takes part)
         return;
     }
     const int c = (int)(i % RC);
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) conv3d_c1_kernel(float* __restrict__ y, c
                     acc = fmaf(x[(((long long)b * D1 + j1) * D2 + j2) * D3 + j3], w[((d1 * 3 + d2) * 3 + d3) * RC + c], acc);
             }
     y[i] = acc;
-    if (amax) r3_wave_amax(acc, amax);
+    if (amax) r3_block_amax(acc, amax);
 }
 
 // ---- attention gate: global average pool finish + 1x1 squeeze (ReLU) + 1x1 excite (sigmoid) ---------------------
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__
         v = fmaf(y[i], gate[b * C + c], res[i]);
         out[i] = v;
     }
-    if (amax) r3_wave_amax(v, amax);
+    if (amax) r3_block_amax(v, amax);
 }
 
 // the same for C = 32 with 16-byte accesses; one batch element per blockIdx.y (no 64-bit divisions)
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) scale_residual_c32_kernel(float* __restri
         }
         o4[i] = v;
     }
-    if (amax) r3_wave_amax(m, amax);
+    if (amax) r3_block_amax(m, amax);
 }
 
 __global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const float* __restrict__ a,
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) add_kernel(float* __restrict__ out, const
         v = a[i] + b[i];
         out[i] = v;
     }
-    if (amax) r3_wave_amax(v, amax);
+    if (amax) r3_block_amax(v, amax);
 }
 
 // (x - MEAN)/STD  (network.py:21-23)
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(256) add_v4_kernel(float* __restrict__ out, co
         }
         reinterpret_cast<f32x4*>(out)[i] = v;
     }
-    if (amax) r3_wave_amax(m, amax);
+    if (amax) r3_block_amax(m, amax);
 }
 
 // stem with four output channels per thread (one 16-byte store; the 27 inputs are read once per four outputs)
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) conv3d_c1_v4_kernel(float* __restrict__ y
 #pragma unroll
         for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[q]));
     }
-    if (amax) r3_wave_amax(m, amax);
+    if (amax) r3_block_amax(m, amax);
 }
 
 // ---- 2-D branch (RTAB on the 9 normalised inputs, network.py:145-148): direct kernels ----------------------------
@@ -760,7 +760,8 @@ size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W) {
     const long long slab = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * (int)T) * RC + 4096;
     const long long small = (long long)B * (H + 2) * (W + 2) * T * 4 + (long long)B * H * W * d->scale * d->scale * 2;
     // split-fp16 inference: hi/lo planes of every 32 -> 32 kernel + scale slots
-    const long long h3 = (long long)rams_conv3d_count(d) * (R3_LAYER_HALVES / 2) + 1024;
+    const long long h3 = (long long)rams_conv3d_count(d) * (R3_LAYER_HALVES / 2) + 1024 +
+                         (3ll * rams_conv3d_count(d) + 8) * R3_SLOT;
     return (size_t)(5 * big + slab + small + 8192 + h3);
 }
 
@@ -790,11 +791,14 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     unsigned* slots = reinterpret_cast<unsigned*>(ws + 5 * big + slab_floats + (long long)B * H * W * T +
                                                   3 * (long long)B * (H + 2) * (W + 2) * T + 2 * (long long)B * H * W * S2 + 64);
     slots = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(slots) + 255) & ~(uintptr_t)255);
-    _Float16* planes = reinterpret_cast<_Float16*>(slots + 1024);
-    int conv_no = 0, next_slot = n_conv;      // slots [0, n_conv): max|w| per convolution; the rest: max|x| per tensor
-    auto new_slot = [&]() { return slots + next_slot++; };
+    // words [0, 1024): max|w| per convolution; then R3_MAX_SLOTS tensor slots of R3_SLOT words each; then the weight planes
+    unsigned* tslots = slots + 1024;
+    const int n_slots = 3 * n_conv + 8;       // (at most three new tensors per convolution + stem, skip, ...)
+    _Float16* planes = reinterpret_cast<_Float16*>(tslots + (long long)n_slots * R3_SLOT);
+    int conv_no = 0, next_slot = 0;
+    auto new_slot = [&]() { return tslots + (long long)(next_slot < n_slots - 1 ? next_slot++ : next_slot) * R3_SLOT; };
     if (h3) {
-        INR_HIP(hipMemsetAsync(slots, 0, 1024 * sizeof(unsigned), st));
+        INR_HIP(hipMemsetAsync(slots, 0, (1024 + (size_t)n_slots * R3_SLOT) * sizeof(unsigned), st));
         // the 3-D kernels in consumption order (same walk as below)
         R3SplitJobs jobs{};
         Cursor w{params};
