@@ -1301,7 +1301,7 @@ int inr_debug_set(int key, int value) {
     if (key == 12) { g_small_multi = value; return 0; }
     if (key == 13) { g_small_rows = value; return 0; }
     if (key == 14) { g_rams_h3 = value & 3; g_rams_force_lds = (value >> 2) & 1; return 0; }
-    if (key == 15) { g_rams_lds_waves = value == 8 ? 8 : 4; return 0; }
+    if (key == 15) { g_rams_lds_waves = (value == 8 || value == 16) ? value : 4; return 0; }
     if (key == 16) { g_hp_zhead = value; return 0; }
     if (key == 11) { g_hp_stagger = value; return 0; }
     if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...

@@ -536,11 +536,11 @@ static int conv3d_h3(const float* x, float* y, const _Float16* planes, const flo
 }
 
 // patch of the LDS-staged kernel: the most outputs that fit one round of 8 wave tiles (<= 256) whose halo fits the image
-static void r3l_choose_patch(int D3, int O3, int* PO1, int* PO2) {
+static void r3l_choose_patch(int D3, int O3, int* PO1, int* PO2, int max_hvox = R3L_MAX_HVOX, int max_out = 256) {
     int best = 0, b1 = 1, b2 = 1;
     for (int a = 1; a <= 16; ++a)
         for (int c = a; c <= 32; ++c) {
-            if ((a + 2) * (c + 2) * D3 > R3L_MAX_HVOX || a * c * O3 > 256) continue;
+            if ((a + 2) * (c + 2) * D3 > max_hvox || a * c * O3 > max_out) continue;
             if (a * c > best) { best = a * c; b1 = a; b2 = c; }
         }
     *PO1 = b1;
@@ -561,12 +561,17 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
     p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
     p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
     p.pad = pad; p.cout = cout; p.y_cstride = y_cstride; p.relu = relu;
-    r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
+    const bool two_pass = g_rams_lds_waves == 16;       // 8 waves x 2 tiles, channels in two halves (conv3d_c32_lds2_kernel)
+    if (two_pass) r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2, R3L2_MAX_HVOX, 512);
+    else r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
     p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
     p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
     const int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
     ProfScope ps(KC_OTHER, st);
-    if (g_rams_lds_waves == 8) {
+    if (two_pass) {
+        if (nslab) *nslab = blocks * 8;
+        hipLaunchKernelGGL(conv3d_c32_lds2_kernel, dim3(blocks, B), dim3(512), 0, st, p);
+    } else if (g_rams_lds_waves == 8) {
         if (nslab) *nslab = blocks * 8;
         hipLaunchKernelGGL((conv3d_c32_lds_kernel<8, 1>), dim3(blocks, B), dim3(512), 0, st, p);
     } else {
@@ -819,7 +824,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
                       unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb) -> int {
         const int k = conv_no++;
         last_nslab = wpb;
-        if (h3 && g_rams_h3 == 2 && D3 * 9 <= R3L_MAX_HVOX)  // (a 3 x 3 halo of one output column must fit the image)
+        if (h3 && g_rams_h3 == 2 && D3 * 9 <= R3L_MAX_HVOX)   // (a 3 x 3 halo of one output column must fit the image)
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
                                  pad, cout, cstride, relu, &last_nslab, st);
         if (h3)

@@ -34,8 +34,9 @@ def test_full_size_stack_matches_oracle():
     # every path of the 32 -> 32 convolutions (debug key 14): 6 = split-fp16 MFMA with the activations staged in LDS, forced
     # (the default for batches; batch 1 at this size would take the f32 kernel), 2 = the default rule, 1 = split-fp16 with
     # the activations from global memory, 0 = the exact f32-input MFMA
-    for split, flips in ((6, 2e-2), (2, 2e-2), (1, 2e-2), (0, 1e-2)):
-        lib().inr_debug_set(14, split)
+    for split, flips in ((6, 2e-2), (22, 2e-2), (2, 2e-2), (1, 2e-2), (0, 1e-2)):     # 22: key 14 = 6 with the two-pass kernel
+        lib().inr_debug_set(14, 6 if split == 22 else split)
+        lib().inr_debug_set(15, 16 if split == 22 else DEFAULT_LDS_KERNEL)
         try:
             got = model(x).cpu().numpy()
             assert got.shape == (2, 384, 384, 1)
@@ -50,18 +51,27 @@ def test_full_size_stack_matches_oracle():
             assert frac < flips and np.abs(pt - ref).max() <= 1.0
         finally:
             lib().inr_debug_set(14, 2)
+            lib().inr_debug_set(15, DEFAULT_LDS_KERNEL)
 
 
 @pytest.fixture
 def conv_mode(request):
-    """debug key 14 for the duration of a test: 2 = default rule, 6 = LDS-staged split-fp16 kernel forced, 1 / 0 = the others"""
+    """debug keys 14 / 15 for the duration of a test: key 14 = 2 default rule, 6 LDS-staged split-fp16 kernels forced, 1 / 0 the
+    others; key 15 = which LDS-staged kernel (8: 8 waves x 1 tile, 4: 4 x 2, 16: two-pass 8 x 2)"""
     from mri_super_resolution_amd._lib import lib
-    lib().inr_debug_set(14, request.param)
+    k14, k15 = request.param if isinstance(request.param, tuple) else (request.param, None)
+    lib().inr_debug_set(14, k14)
+    if k15 is not None:
+        lib().inr_debug_set(15, k15)
     yield request.param
     lib().inr_debug_set(14, 2)
+    lib().inr_debug_set(15, DEFAULT_LDS_KERNEL)
 
 
-@pytest.mark.parametrize("conv_mode", [2, 6, 1], indirect=True)
+DEFAULT_LDS_KERNEL = 8
+
+
+@pytest.mark.parametrize("conv_mode", [2, (6, 8), (6, 4), (6, 16), 1], indirect=True)
 @pytest.mark.parametrize("B,H,W", [(1, 24, 20), (3, 16, 16), (2, 13, 31)])
 def test_forward_matches_oracle(B, H, W, conv_mode):
     params = R.init_rams_params(seed=1, perturb_g=True)

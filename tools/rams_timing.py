@@ -6,6 +6,9 @@ if len(sys.argv) > 1:      # arithmetic of the 32 -> 32 convolutions: 1 = split-
     from mri_super_resolution_amd._lib import lib
     lib().inr_debug_set(14, int(sys.argv[1]))
     print('debug key 14 =', sys.argv[1])
+    if len(sys.argv) > 2:
+        lib().inr_debug_set(15, int(sys.argv[2]))
+        print('debug key 15 =', sys.argv[2])
 for B in (1, 5, 25):
     x = (np.random.default_rng(0).random((B, 128, 128, 9)) * 60000).astype(np.float32)
     xt = torch.from_numpy(x).cuda()
