@@ -801,7 +801,10 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     const int n_slots = 3 * n_conv + 8;       // (at most three new tensors per convolution + stem, skip, ...)
     _Float16* planes = reinterpret_cast<_Float16*>(tslots + (long long)n_slots * R3_SLOT);
     int conv_no = 0, next_slot = 0;
-    auto new_slot = [&]() { return tslots + (long long)(next_slot < n_slots - 1 ? next_slot++ : next_slot) * R3_SLOT; };
+    auto new_slot = [&]() {     // (a graph with more tensors than slots would share the last one: a larger maximum, still a valid scale)
+        const int k = next_slot < n_slots - 1 ? next_slot++ : n_slots - 1;
+        return tslots + (long long)k * R3_SLOT;
+    };
     if (h3) {
         INR_HIP(hipMemsetAsync(slots, 0, (1024 + (size_t)n_slots * R3_SLOT) * sizeof(unsigned), st));
         // the 3-D kernels in consumption order (same walk as below)
