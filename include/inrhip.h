@@ -343,8 +343,11 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * default, 0 = 128 x 128); key 7 = pre-split (HL32) operand path of the fused entry points (1 default); key 10 = its
  * kernel family (2 = persistent with deferred epilogue, default; 1 = persistent, epilogue in line; 0 = one block per
  * tile); key 11 = start stagger between CUs of the persistent kernels (K-steps x 100, 0 default); key 12 = small-network
- * fit (1 = persistent multi-step kernel, default; 0 = two launches per step); keys 8/9 = time-stamp selection of
- * diagnostic builds */
+ * fit (1 = persistent multi-step kernel, default; 0 = two launches per step); key 13 = its rows per block (0 choose,
+ * 32, 64); key 14 = RAMS 32->32 convolutions (2 = split-fp16 MFMA, activations staged in LDS, default; 1 = split-fp16,
+ * activations from global memory; 0 = f32-input MFMA; +4 forces the LDS-staged kernels); key 15 = which LDS-staged kernel
+ * (8 = 8 waves x 1 tile, default; 4 = 4 waves x 2 tiles; 16 = two-pass 8 waves x 2 tiles); key 16 = last sine layer of a
+ * fit step stashes z only (1 default, 0 = act + omega cos); keys 8/9 = time-stamp selection of diagnostic builds */
 int inr_debug_set(int key, int value);
 int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds);
                                                  key 1: device scratch for debug key 3 = 2 */
