@@ -399,7 +399,9 @@ def main():
                     "mfma_view": {"achieved_tflops_fp32_equivalent": achieved, "peak_tflops_fp32_equivalent": mfma_peak,
                                   "frac": achieved / mfma_peak,
                                   "note": "algorithmic FLOP / time against dense fp16 MFMA peak / 3 products"},
-                    "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+                    "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "power_note": "peaks are the nominal 2.4 GHz figures; during these steps the package sits at its 1,400 W cap "
+                                  "and the shader clock at ~1.76 GHz (rocm-smi, profiles/r02_power.txt, tools/clock_watch.sh)"}
     ops.prof_reset()
 
     out = {"metric": "voxels/sec per INR fit (128^3, x4 upscale): train coordinate-steps/s",
