@@ -373,7 +373,8 @@ def _set_small_kernel(persistent):
     lib().inr_debug_set(12, 1 if persistent else 0)
 
 
-@pytest.mark.parametrize("hidden,layers,side,feat", [(64, 6, 60, 2), (32, 2, 25, 2), (64, 1, 37, 5), (32, 0, 9, 2)])
+@pytest.mark.parametrize("hidden,layers,side,feat", [(64, 6, 60, 2), (32, 2, 25, 2), (64, 1, 37, 5), (32, 0, 9, 2),
+                                                      (64, 2, 20, 32), (32, 1, 16, 17), (64, 3, 100, 3)])
 def test_small_net_persistent_kernel_matches_the_two_launch_path(hidden, layers, side, feat):
     """master.py regime: 3 acquisitions cycling through 13 optimizer steps (targets and weights change every step) inside
     ONE persistent launch, against the same steps taken one by one through the step kernel + reduce/Adam kernel pair.
