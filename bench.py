@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -84,6 +85,23 @@ def cpu_baseline(n_sample, steps, warmup, B_np, vol, thread_counts):
             "sample": f"first {n_sample} of 524288 LR rows of the synthetic 128^3 fit, {steps} steps after {warmup} warm-up per "
                       f"thread count, torch {torch.__version__} CPU ({os.cpu_count()} logical CPUs visible)",
             "seconds": best["seconds"], "thread_sweep": runs}
+
+
+def sample_power(out):
+    """One `rocm-smi` reading (shader clock, package power) taken from a timer thread while the long fit runs: the fused steps
+    are power-limited, so the clock the GPU actually holds belongs next to the throughput."""
+    import re
+    import subprocess
+    try:
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+        m = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+        w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+        if m:
+            out["sclk_mhz"] = int(m.group(1))
+        if w:
+            out["package_watts"] = float(w.group(1))
+    except Exception as e:  # noqa: BLE001 -- telemetry is optional
+        out["error"] = str(e)[:100]
 
 
 def cfg1_quality(inr, steps=2500, seeds=tuple(range(12))):
@@ -457,17 +475,22 @@ def main():
             torch.manual_seed(0)
             net_full = inr.Siren(IN_F, HIDDEN, LAYERS, OUT_F).cuda()
             torch.cuda.synchronize()
+            telemetry = {}
+            sampler = threading.Timer(6.0, sample_power, args=(telemetry,))   # the steps are enqueued at once: the GPU is ~6 s in
+            sampler.start()
             t0 = time.perf_counter()
             _, full_losses = inr.fit_siren(net_full, x, target, 2500, lr=1e-4)
             torch.cuda.synchronize()
             t_fit = time.perf_counter() - t0
+            sampler.join()
             t0 = time.perf_counter()
             rec = inr.reconstruct(net_full, grid3, B)
             torch.cuda.synchronize()
             t_inf = time.perf_counter() - t0
             out["full_fit"] = {"steps": 2500, "t_fit_s": t_fit, "t_recon_s": t_inf,
                                "train_voxels_per_s": n_lr * 2500 / t_fit, "recon_voxels_per_s": n_test / t_inf,
-                               "e2e_voxels_per_s": n_test / (t_fit + t_inf), "final_loss": float(full_losses[-1])}
+                               "e2e_voxels_per_s": n_test / (t_fit + t_inf), "final_loss": float(full_losses[-1]),
+                               "power_during_fit": telemetry or None}
             del rec, net_full
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
