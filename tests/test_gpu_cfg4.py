@@ -72,6 +72,30 @@ def test_eleven_patients_two_ranks_with_a_gang(golden):
     assert all(np.isfinite(r["final_loss"]) for r in recs0)
 
 
+def _two_gang_worker(rank, world, steps):
+    from tests.conftest import GOLDEN
+    import os
+    rest = np.load(os.path.join(GOLDEN, "patients_mean_b0.npz"))
+    from mri_super_resolution_amd import drivers as drv
+    return drv.run_volumes([rest["pat76"], rest["pat78"]], steps=steps, seed=0, chunk_steps=steps)
+
+
+def test_two_gangs_run_side_by_side(golden):
+    """4 ranks (gloo, all on the test GPU), the two 34-slice volumes: the plan gives each its own pair of ranks -- two process
+    groups created collectively, two row-sharded fits running at the same time -- and every rank ends with both records,
+    each matching the single-process fit of its volume."""
+    rest = golden("patients_mean_b0.npz")
+    vols = [rest["pat76"], rest["pat78"]]
+    plan = inr_dist.plan_fits([float(64 * 64 * 34) * 8] * 2, 4)
+    assert plan["gangs"] == [(0, [0, 1]), (1, [2, 3])] and all(len(w) == 0 for w in plan["whole"])
+    recs = run_ranks(_two_gang_worker, 4, (8,), timeout=600)
+    assert all(r == recs[0] for r in recs) and [int(r["job"]) for r in recs[0]] == [0, 1]
+    for j, v in enumerate(vols):
+        single = drivers.fit_volume(v, steps=8, seed=0, chunk_steps=8, return_recon=False)
+        assert recs[0][j]["final_loss"] == pytest.approx(single["final_loss"], rel=2e-3)
+        assert recs[0][j]["psnr_db"] == pytest.approx(single["psnr_db"], abs=0.05)
+
+
 def test_full_length_fit_quality_t4(golden):
     """Tier T4: the full 2,500-step config-1 fit (pat07 slice 11, x2) is judged on PSNR over seeds 0-11 against the REAL
     reference run through the same twelve seeds (tests/golden/cfg1_ref_psnr.npz, written by oracle/gen_golden_t4.py:
