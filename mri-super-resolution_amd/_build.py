@@ -61,6 +61,20 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libinrhip.so")
     os.makedirs(OBJ, exist_ok=True)
+    # several ranks of one job may find the library stale at the same moment: one builds, the others wait and re-check
+    import fcntl
+    lock = open(os.path.join(OBJ, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not _stale():
+            return LIB_PATH
+        return _build_locked(hipcc, force, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
     newest_header = max(os.path.getmtime(h) for h in _headers())
     jobs = []
     for src in _sources():
