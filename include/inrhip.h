@@ -13,7 +13,18 @@
  *    void* (0 = the null stream).  No torch types, no ownership transfer: the caller allocates every
  *    output and every workspace (size from the matching *_workspace_bytes query).
  *  - every function only ENQUEUES work on `stream` and returns without synchronising (graph-capture
- *    safe: no allocation, no host sync inside).
+ *    safe: no allocation, no host sync inside).  ONE exception: when inr_siren_fit / inr_siren_fit_cycle
+ *    take the persistent cooperative small-network kernel (hidden 32 / 64, <= 32 input features, one
+ *    output, few thousand rows) they wait for the stream once at the end of the call to read the
+ *    kernel's completion word, and return INR_E_TIMEOUT if a launch was abandoned (cooperative launches
+ *    cannot be captured into a graph in any case).
+ *  - threading: entry points may be called concurrently from several host threads on different streams
+ *    with disjoint buffers; the library keeps no per-call state.  Process-global state is limited to
+ *    (i) the event profiler behind inr_prof_*, (ii) the launch counters behind inr_launch_count and
+ *    (iii) the DIAGNOSTIC switches behind inr_debug_set / inr_debug_set_ptr, which select kernel families
+ *    for A/B measurements and tests.  The switches are atomics, but they are process-wide: flipping one
+ *    while another thread is enqueueing changes what that thread launches next.  A production caller
+ *    never touches them; a test harness restores them with inr_debug_reset().
  *  - return value: 0 = ok; negative = invalid argument (INR_E_*); positive = hipError_t.
  *    inr_last_error() returns a thread-local human-readable message for the last failure.
  *  - all tensors are dense row-major fp32.  Linear weights are [out_features][in_features] exactly as
@@ -36,6 +47,8 @@ extern "C" {
 #define INR_E_INVALID   (-1)  /* null pointer / non-positive size / unsupported shape            */
 #define INR_E_WORKSPACE (-2)  /* workspace pointer null or smaller than the *_workspace_bytes query */
 #define INR_E_ALIGN     (-3)  /* pointer not 16-byte aligned where the kernel requires it         */
+#define INR_E_TIMEOUT   (-4)  /* a persistent kernel abandoned its launch (grid barrier poll limit): outputs of the call are
+                                 partly written and must be discarded                                */
 
 typedef struct inr_device_caps {
     int  abi_version;
@@ -347,10 +360,32 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * 32, 64); key 14 = RAMS 32->32 convolutions (2 = split-fp16 MFMA, activations staged in LDS, default; 1 = split-fp16,
  * activations from global memory; 0 = f32-input MFMA; +4 forces the LDS-staged kernels); key 15 = which LDS-staged kernel
  * (8 = 8 waves x 1 tile, default; 4 = 4 waves x 2 tiles; 16 = two-pass 8 waves x 2 tiles); key 16 = last sine layer of a
- * fit step stashes z only (1 default, 0 = act + omega cos); keys 8/9 = time-stamp selection of diagnostic builds */
-int inr_debug_set(int key, int value);
+ * fit step stashes z only (1 default, 0 = act + omega cos); key 17 = poll limit of the small-network kernel's grid barrier (0 = built-in 2^22;
+ * tests force the abandon path with 1); key 18 = 64-row tiles for GEMM launches with too few 128-row tiles to fill the chip
+ * (1 default); keys 8/9 = time-stamp selection of diagnostic builds.
+ * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
+int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */
+int inr_debug_get(int key, int* value);    /* the value a key currently holds */
+int inr_debug_reset(void);                 /* every key (and both inr_debug_set_ptr pointers) back to its default */
 int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffer (only honoured by -DINR_STAMPS builds);
                                                  key 1: device scratch for debug key 3 = 2 */
+
+/* Launch-family counters (process-global, monotonic until reset): how many launches each kernel family has received from
+ * the host launchers since the last inr_launch_counts_reset().  Lets a parity test assert WHICH family it covered. */
+#define INR_LF_HP_PKD      0   /* gemm_hp_pkd_kernel: HL32 operands, persistent grid, epilogue deferred under the next K-loop */
+#define INR_LF_HP_PKC      1   /* gemm_hp_pkc_kernel: HL32 operands, persistent grid, epilogue in line */
+#define INR_LF_HP_TILE     2   /* gemm_hp_kernel<KC>: HL32 operands, one block per tile */
+#define INR_LF_HP_RC       3   /* gemm_hp_kernel<RC>: HL32 parameter gradient */
+#define INR_LF_H3          4   /* gemm_h3_kernel: split-fp16, fp32 operands split by the consumer */
+#define INR_LF_F32_PIPE16  5   /* gemm_f32_pipe16_kernel: f32-input MFMA 16x16x4 */
+#define INR_LF_F32_PIPE    6   /* gemm_f32_pipe_kernel: f32-input MFMA 32x32x2 */
+#define INR_LF_F32_GENERIC 7   /* gemm_f32_kernel: guarded generic kernel */
+#define INR_LF_SMALL_MULTI 8   /* siren_small_multi_kernel: persistent cooperative small-network fit */
+#define INR_LF_SMALL_STEP  9   /* small-network step kernel + reduce/Adam kernel */
+#define INR_LF_HP_NARROW   10  /* gemm_hp_pkn_kernel: HL32 operands, persistent grid, 64-row tiles */
+#define INR_LF_COUNT       11
+int inr_launch_count(int family, int64_t* count);
+int inr_launch_counts_reset(void);
 
 /* diagnostic: s[i] = sin(x[i]), c[i] = cos(x[i]) with the device routine used in the epilogues */
 int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream);

@@ -43,13 +43,17 @@ def build_diagnostic(defines=("-DINR_STAMPS",), out=None, verbose=False) -> str:
     ``INR_LIB=<path>``; ``inr_build_flags()`` of such a library is non-zero and the binding refuses it otherwise."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = out or os.path.join(PKG_DIR, "libinrhip_diag.so")
-    cmd = [hipcc] + FLAGS + list(defines) + ["-shared", "-I", INCLUDE, "-I", CSRC, "-o", out] + \
+    tmp = f"{out}.tmp.{os.getpid()}"
+    cmd = [hipcc] + FLAGS + list(defines) + ["-shared", "-I", INCLUDE, "-I", CSRC, "-o", tmp] + \
         [os.path.join(CSRC, s) for s in _sources()]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, out)          # readers only ever see a complete file
     return out
 
 
@@ -93,10 +97,17 @@ def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
             if res.returncode != 0:
                 raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in _sources()]
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    # Link beside the target and rename over it: the unlocked `_stale()` fast path of another rank (and `_lib.lib()`, which
+    # never takes the lock) then only ever sees a COMPLETE library, and a process that has the old file mapped keeps its
+    # (unlinked) inode instead of having the pages rewritten under it.
+    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     res = run(link)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

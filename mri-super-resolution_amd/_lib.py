@@ -15,6 +15,10 @@ c_i64p = C.POINTER(C.c_int64)
 c_stream = C.c_void_p
 
 
+INR_E_INVALID, INR_E_WORKSPACE, INR_E_ALIGN, INR_E_TIMEOUT = -1, -2, -3, -4     # include/inrhip.h
+INR_LF_COUNT = 11
+
+
 class InrHipError(RuntimeError):
     """A libinrhip.so entry point returned a non-zero status."""
 
@@ -127,6 +131,10 @@ SIGNATURES = {
     "inr_prof_reset": (C.c_int, []),
     "inr_prof_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),
     "inr_debug_set": (C.c_int, [C.c_int, C.c_int]),
+    "inr_debug_get": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "inr_debug_reset": (C.c_int, []),
+    "inr_launch_count": (C.c_int, [C.c_int, c_i64p]),
+    "inr_launch_counts_reset": (C.c_int, []),
     "inr_debug_set_ptr": (C.c_int, [C.c_int, C.c_void_p]),
     "inr_sincos_probe": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, c_stream]),
 }

@@ -41,6 +41,12 @@ struct ProfState {
 };
 static ProfState g_prof;
 bool prof_enabled() { return g_prof.enabled; }
+
+// ---- launch-family counters (inr_launch_count) ------------------------------------------------------------------------
+static std::atomic<long long> g_launches[LF_COUNT];
+void count_launch(int family) {
+    if (family >= 0 && family < LF_COUNT) g_launches[family].fetch_add(1, std::memory_order_relaxed);
+}
 // scopes of one class may nest (a launcher calling another launcher): only the outermost pair is recorded
 void prof_begin(int kc, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -79,7 +85,7 @@ int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
                     int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false);
 bool hp_z_stash_ok(int in_f);
-extern int g_hp_zhead;
+extern tune_int g_hp_zhead;
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
                   float* colsum_slab, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so, hipStream_t stream);
 int hp_param_grad_splits(int64_t n, int in_f, int out_f);
@@ -167,19 +173,19 @@ int small_fit_multi(const inr_siren_desc_t* d, const long long* w_off, const lon
 int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long long* b_off, long long P, float* params,
                    float* grads, float* m, float* v, const float* x, const float* target, const float* weight, int64_t n,
                    int64_t step, double lr, double b1, double b2, double eps, float* loss_out, float* ws, hipStream_t st);
-extern int g_force_generic;
-extern int g_small_rows;
-extern int g_rams_h3, g_rams_force_lds, g_rams_lds_waves;
-int g_small_multi = 1;   // small networks: 1 = persistent multi-step kernel (default), 0 = two launches per step
-extern int g_mfma16;
-extern int g_h3;
-extern int g_h3_wide;
-static int g_h3_serpentine = 1;
-static int g_hp = 1;   // pre-split (HL32) GEMM path inside the fused entry points; inr_debug_set(7, 0) falls back to gemm_h3
+extern tune_int g_force_generic;
+extern tune_int g_small_rows, g_small_spin_limit;
+extern tune_int g_rams_h3, g_rams_force_lds, g_rams_lds_waves;
+tune_int g_small_multi{1};  // small networks: 1 = persistent multi-step kernel (default), 0 = two launches per step
+extern tune_int g_mfma16;
+extern tune_int g_h3;
+extern tune_int g_h3_wide;
+static tune_int g_h3_serpentine{1};
+static tune_int g_hp{1};  // pre-split (HL32) GEMM path inside the fused entry points; inr_debug_set(7, 0) falls back to gemm_h3
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
-extern int g_stamp_class, g_stamp_nth;
-extern int g_hp_persistent, g_hp_stagger;
+extern tune_int g_stamp_class, g_stamp_nth;
+extern tune_int g_hp_persistent, g_hp_stagger, g_hp_narrow;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
 static const int64_t MAX_ROWS = (1ll << 31) - 256;
@@ -947,9 +953,12 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
         // launch per step instead of ~45 layer-wise launches (csrc/siren_small.hip)
         long long w_off[32], b_off[32];
         for (int l = 0; l <= L.n_sine; ++l) { w_off[l] = L.w_off[l]; b_off[l] = L.b_off[l]; }
-        if (g_small_multi && small_multi_ok(desc, n))   // all steps inside one persistent launch per 64 steps
-            return small_fit_multi(desc, w_off, b_off, L.total, params, grads, m, v, x, targets, weights, n_acq, first_acq, n,
-                                   first_step, n_steps, lr, beta1, beta2, eps, losses, (float*)workspace, st);
+        if (g_small_multi && small_multi_ok(desc, n)) {   // all steps inside one persistent launch per 64 steps
+            const int rc = small_fit_multi(desc, w_off, b_off, L.total, params, grads, m, v, x, targets, weights, n_acq,
+                                           first_acq, n, first_step, n_steps, lr, beta1, beta2, eps, losses,
+                                           (float*)workspace, st);
+            if (rc != INR_E_FALLBACK) return rc;   // (a device that cannot hold the grid co-resident: two launches per step)
+        }
         for (int it = 0; it < n_steps; ++it) {
             const int64_t a = (first_acq + it) % n_acq;
             if (int rc = small_fit_step(desc, w_off, b_off, L.total, params, grads, m, v, x, targets + a * acq_stride,
@@ -1290,24 +1299,84 @@ int inr_debug_set_ptr(int key, void* ptr) {
     return INR_E_INVALID;
 }
 
+// ---- diagnostic switches ------------------------------------------------------------------------------------------------
+// One table: key -> switch, default, accepted range.  Process-global (see the header): every value is an atomic, so a switch can
+// be read while another thread sets it, but a set is visible to every thread's next launch.
+namespace {
+struct DebugKey {
+    int key;
+    tune_int* var;
+    int def, lo, hi;
+};
+tune_int g_rams_mode{2}, g_hybrid_mirror{1};   // (keys 14 and 2 fan out to other variables: kept here for inr_debug_get)
+const DebugKey* debug_table(int* count) {
+    static const DebugKey table[] = {
+        {0, &g_force_generic, 0, 0, 1},   {1, &g_mfma16, 1, 0, 1},          {2, &g_hybrid_mirror, 1, 0, 1},
+        {3, &g_h3, 1, 0, 2},              {5, &g_h3_serpentine, 1, 0, 1},   {6, &g_h3_wide, 1, 0, 1},
+        {7, &g_hp, 1, 0, 1},              {8, &g_stamp_class, -1, -1, 3},   {9, &g_stamp_nth, 0, 0, 1 << 30},
+        {10, &g_hp_persistent, 2, 0, 2},  {11, &g_hp_stagger, 0, 0, 1 << 20}, {12, &g_small_multi, 1, 0, 1},
+        {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 8, 4, 16},
+        {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
+    };
+    *count = (int)(sizeof(table) / sizeof(table[0]));
+    return table;
+}
+void debug_apply(const DebugKey& k, int value) {
+    if (k.key == 14) {
+        g_rams_h3 = value & 3;
+        g_rams_force_lds = (value >> 2) & 1;
+    } else if (k.key == 15) {
+        value = (value == 8 || value == 16) ? value : 4;
+    } else if (k.key == 2) {
+        set_hybrid_variant(value);
+    }
+    k.var->store(value);
+}
+}  // namespace
+
 int inr_debug_set(int key, int value) {
-    if (key == 0) { g_force_generic = value; return 0; }
-    if (key == 1) { g_mfma16 = value; return 0; }
-    if (key == 3) { g_h3 = value; return 0; }
-    if (key == 5) { g_h3_serpentine = value; return 0; }
-    if (key == 6) { g_h3_wide = value; return 0; }
-    if (key == 7) { g_hp = value; return 0; }
-    if (key == 10) { g_hp_persistent = value; return 0; }
-    if (key == 12) { g_small_multi = value; return 0; }
-    if (key == 13) { g_small_rows = value; return 0; }
-    if (key == 14) { g_rams_h3 = value & 3; g_rams_force_lds = (value >> 2) & 1; return 0; }
-    if (key == 15) { g_rams_lds_waves = (value == 8 || value == 16) ? value : 4; return 0; }
-    if (key == 16) { g_hp_zhead = value; return 0; }
-    if (key == 11) { g_hp_stagger = value; return 0; }
-    if (key == 8) { g_stamp_class = value; return 0; }   // diagnostic builds: stamp only launches of this kernel class ...
-    if (key == 9) { g_stamp_nth = value; return 0; }     // ... and only the n-th one since this call (counts down)
-    if (key == 2) { set_hybrid_variant(value); return 0; }
-    return INR_E_INVALID;
+    int n = 0;
+    const DebugKey* t = debug_table(&n);
+    for (int i = 0; i < n; ++i)
+        if (t[i].key == key) {
+            INR_REQUIRE(value >= t[i].lo && value <= t[i].hi, INR_E_INVALID, "inr_debug_set: key %d takes %d .. %d (got %d)", key,
+                        t[i].lo, t[i].hi, value);
+            debug_apply(t[i], value);
+            return 0;
+        }
+    INR_REQUIRE(false, INR_E_INVALID, "inr_debug_set: unknown key %d", key);
+}
+
+int inr_debug_get(int key, int* value) {
+    INR_REQUIRE(value != nullptr, INR_E_INVALID, "inr_debug_get: null pointer");
+    int n = 0;
+    const DebugKey* t = debug_table(&n);
+    for (int i = 0; i < n; ++i)
+        if (t[i].key == key) {
+            *value = t[i].var->load();
+            return 0;
+        }
+    INR_REQUIRE(false, INR_E_INVALID, "inr_debug_get: unknown key %d", key);
+}
+
+int inr_debug_reset(void) {
+    int n = 0;
+    const DebugKey* t = debug_table(&n);
+    for (int i = 0; i < n; ++i) debug_apply(t[i], t[i].def);
+    g_stamps = nullptr;
+    g_h3_scratch = nullptr;
+    return 0;
+}
+
+int inr_launch_count(int family, int64_t* count) {
+    INR_REQUIRE(family >= 0 && family < LF_COUNT && count, INR_E_INVALID, "inr_launch_count: bad arguments");
+    *count = (int64_t)g_launches[family].load(std::memory_order_relaxed);
+    return 0;
+}
+
+int inr_launch_counts_reset(void) {
+    for (int f = 0; f < LF_COUNT; ++f) g_launches[f].store(0, std::memory_order_relaxed);
+    return 0;
 }
 
 int inr_sincos_probe(float* s, float* c, const float* x, int64_t n, void* stream) {

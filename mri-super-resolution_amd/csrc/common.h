@@ -1,6 +1,8 @@
 // Shared host/device helpers for libinrhip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -62,6 +64,29 @@ struct HpScale {
     const float* wn = nullptr;        // device float, nullable
     float mul = 0.f;                  // 0 = no scale at all (tensor in [-1, 1]: sine outputs)
 };
+
+// Process-global diagnostic switches behind inr_debug_set (atomics: a read races with nothing, but a switch flipped while
+// another thread is enqueueing changes that thread's kernel selection -- diagnostic use only, see include/inrhip.h).
+typedef std::atomic<int> tune_int;
+
+// Which kernel family a host launcher picked: counted per process so that a test can assert that the family it means to
+// cover is the one that ran (inr_launch_count).  Keep in step with INR_LF_* in include/inrhip.h.
+enum LaunchFamily {
+    LF_HP_PKD = 0,      // gemm_hp_pkd_kernel   persistent, deferred epilogue (HL32 operands)
+    LF_HP_PKC = 1,      // gemm_hp_pkc_kernel   persistent, epilogue in line
+    LF_HP_TILE = 2,     // gemm_hp_kernel<HP_KC> one block per tile
+    LF_HP_RC = 3,       // gemm_hp_kernel<HP_RC> parameter gradient (row contraction)
+    LF_H3 = 4,          // gemm_h3_kernel       split-fp16, operands split in the consumer
+    LF_F32_PIPE16 = 5,  // gemm_f32_pipe16_kernel
+    LF_F32_PIPE = 6,    // gemm_f32_pipe_kernel
+    LF_F32_GENERIC = 7, // gemm_f32_kernel
+    LF_SMALL_MULTI = 8, // siren_small_multi_kernel (persistent cooperative)
+    LF_SMALL_STEP = 9,  // siren_small step kernel pair
+    LF_HP_NARROW = 10,  // gemm_hp_pkn_kernel   persistent 64-row tiles (few-row launches)
+    LF_COUNT = 11
+};
+void count_launch(int family);
+#define INR_E_FALLBACK (-100)   // internal: the chosen kernel cannot run on this device, the caller takes its next-best path
 
 enum KernelClass { KC_GEMM_FWD = 0, KC_GEMM_DX = 1, KC_GEMM_DW = 2, KC_OTHER = 3, KC_COUNT = 4 };
 bool prof_enabled();

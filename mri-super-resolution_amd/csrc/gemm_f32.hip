@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const Gemm
 #include "gemm_hp.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
-int g_stamp_class = -1, g_stamp_nth = 0; // hp kernels: which launch receives g_stamps (class, countdown)
+tune_int g_stamp_class{-1}, g_stamp_nth{0}; // hp kernels: which launch receives g_stamps (class, countdown)
 int gemm_build_flags() {
     int f = 0;
 #ifdef INR_STAMPS
@@ -828,11 +828,11 @@ static unsigned long long* hp_stamp_target(int kernel_class) {
     if (!g_stamps || kernel_class != g_stamp_class) return nullptr;
     return g_stamp_nth-- == 0 ? g_stamps : nullptr;
 }
-int g_force_generic = 0;  // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
-int g_mfma16 = 1;         // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
-int g_h3 = 1;             // split-fp16 GEMMs: 0 off, 1 on where the caller supplies scales/planes (fused fit), 2 also in
+tune_int g_force_generic{0}; // tuning/debug: inr_debug_set(0, 1) routes every GEMM through the generic kernel
+tune_int g_mfma16{1};     // 1 = 16x16x4 pipelined kernel (default, faster); inr_debug_set(1, 0) selects the 32x32x2 one
+tune_int g_h3{1};         // split-fp16 GEMMs: 0 off, 1 on where the caller supplies scales/planes (fused fit), 2 also in
                           // the standalone layer calls (debug: planes and amax built per call in g_h3_scratch)
-int g_h3_wide = 1;        // forward GEMMs on 128 x 256 tiles (inr_debug_set(6, 0): 128 x 128 everywhere)
+tune_int g_h3_wide{1};    // forward GEMMs on 128 x 256 tiles (inr_debug_set(6, 0): 128 x 128 everywhere)
 char* g_h3_scratch = nullptr;   // inr_debug_set_ptr(1, ...): >= 16 MB of device memory for mode 2
 
 // ---- host-side launch --------------------------------------------------------------------------
@@ -870,6 +870,7 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
                 hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_KC, H3_SPLIT_KC, false, false, EPI, 2>), grid, block, 0, stream, p);
             }
             INR_LAUNCH_CHECK();
+            count_launch(LF_H3);
             return 0;
         }
     }
@@ -880,6 +881,7 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
             else
                 hipLaunchKernelGGL((gemm_h3_kernel<H3_F32_RC, H3_F32_RC, true, false, EPI, 2>), grid, block, 0, stream, p);
             INR_LAUNCH_CHECK();
+            count_launch(LF_H3);
             return 0;
         }
     }
@@ -892,6 +894,7 @@ static int launch_gemm(GemmParams p, bool vec, hipStream_t stream, bool* used_fa
     else
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, EPI, false>), grid, block, 0, stream, p);
     INR_LAUNCH_CHECK();
+    count_launch(fast ? (g_mfma16 ? LF_F32_PIPE16 : LF_F32_PIPE) : LF_F32_GENERIC);
     return 0;
 }
 
@@ -1096,8 +1099,8 @@ int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float
 // =====================================================================================================
 // host side of the pre-split path (gemm_hp.inc)
 // =====================================================================================================
-int g_hp_stagger = 0;      // inr_debug_set(11, n): start phases of the persistent blocks, n * 64 cycles apart (0 = together)
-int g_hp_persistent = 2;   // inr_debug_set(10, v): 2 persistent walk with the epilogue of tile T under the K-loop of tile T+1
+tune_int g_hp_stagger{0};  // inr_debug_set(11, n): start phases of the persistent blocks, n * 64 cycles apart (0 = together)
+tune_int g_hp_persistent{2}; // inr_debug_set(10, v): 2 persistent walk with the epilogue of tile T under the K-loop of tile T+1
                            // (K = 256 / 512), 1 persistent walk with the epilogue in line, 0 one block per tile
 static int hp_num_cus() {
     static int n = 0;
@@ -1165,7 +1168,8 @@ static int hp_check_grid(const HpParams& p) {
 
 // act (HL32 [n][out_f]) = sin(omega (x W^T + b)); dact (fp32, nullable) = omega cos(.)
 // may the last sine layer of a fit step stash z only (HPE_Z)?  (deferred-epilogue kernel shapes; debug key 16)
-int g_hp_zhead = 1;
+tune_int g_hp_zhead{1};
+tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
 bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
 
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
@@ -1189,6 +1193,7 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
         INR_REQUIRE(dact && hp_z_stash_ok(in_f), INR_E_INVALID, "hp_sine_forward: z-only stash needs the deferred-epilogue kernel");
         if (in_f == 512) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 16>), pgrid, block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 8>), pgrid, block, 0, stream, p);
+        count_launch(LF_HP_PKD);
     } else if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
         if (in_f == 512) {
             if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 16>), pgrid, block, 0, stream, p);
@@ -1197,13 +1202,17 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
             if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 8>), pgrid, block, 0, stream, p);
             else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 8>), pgrid, block, 0, stream, p);
         }
+        count_launch(LF_HP_PKD);
     } else if (g_hp_persistent && in_f >= 3 * HP_BK) {
         if (dact) hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE_STASH>), pgrid, block, 0, stream, p);
         else hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE>), pgrid, block, 0, stream, p);
+        count_launch(LF_HP_PKC);
     } else if (dact) {
         hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
+        count_launch(LF_HP_TILE);
     } else {
         hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
+        count_launch(LF_HP_TILE);
     }
     INR_LAUNCH_CHECK();
     return 0;
@@ -1229,10 +1238,13 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
     const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
     if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
         hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_MUL, 16>), pgrid, block, 0, stream, p);
+        count_launch(LF_HP_PKD);
     } else if (g_hp_persistent && out_f >= 3 * HP_BK) {
         hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_MUL>), pgrid, block, 0, stream, p);
+        count_launch(LF_HP_PKC);
     } else {
         hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
+        count_launch(LF_HP_TILE);
     }
     INR_LAUNCH_CHECK();
     return 0;
@@ -1278,6 +1290,7 @@ int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char*
     ProfScope ps(KC_GEMM_DW, stream);
     hipLaunchKernelGGL((gemm_hp_kernel<HP_RC, HPE_SLAB>), grid, block, 0, stream, p);
     INR_LAUNCH_CHECK();
+    count_launch(LF_HP_RC);
     return 0;
 }
 

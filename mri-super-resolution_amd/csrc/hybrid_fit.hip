@@ -844,7 +844,7 @@ __global__ void __launch_bounds__(64) hybrid_fit_g8_kernel(double* __restrict__ 
     }
 }
 
-static int g_hybrid_variant = 1;   // 1 = eight lanes per voxel (default), 0 = one lane per voxel (cross-check)
+static tune_int g_hybrid_variant{1};   // 1 = eight lanes per voxel (default), 0 = one lane per voxel (cross-check)
 void set_hybrid_variant(int v) { g_hybrid_variant = v; }
 
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,

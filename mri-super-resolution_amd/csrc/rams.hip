@@ -506,10 +506,10 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 }
 
 int rams_waves_per_b(int B, int ovox);
-int g_rams_lds_waves = 8;   // LDS-staged kernel: 8 waves x 1 tile per block (default: 33.2 ms per 25 stacks) or 4 waves x 2 tiles
+tune_int g_rams_lds_waves{8};   // LDS-staged kernel: 8 waves x 1 tile per block (default: 33.2 ms per 25 stacks) or 4 waves x 2 tiles
                             // sharing the weight fragments (34.6 ms: one wave per SIMD hides less latency than it saves bytes)
-int g_rams_force_lds = 0;   // (kept for the debug key's bit 2; the LDS-staged kernel is the default at every batch size now)
-int g_rams_h3 = 2;   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
+tune_int g_rams_force_lds{0};   // (kept for the debug key's bit 2; the LDS-staged kernel is the default at every batch size now)
+tune_int g_rams_h3{2};   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
                      // activations from global; 0 = f32-input MFMA
 
 static int conv3d_h3(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,

@@ -372,6 +372,7 @@ int small_fit_step(const inr_siren_desc_t* d, const long long* w_off, const long
     else
         hipLaunchKernelGGL(siren_small_step_kernel<32>, dim3(blocks), dim3(256), 0, st, p);
     INR_LAUNCH_CHECK();
+    count_launch(LF_SMALL_STEP);
     const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
     hipLaunchKernelGGL(small_reduce_adam_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, st, params, grads, m, v,
                        p.slabs, nwaves, P, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)(lr / bc1),
@@ -417,6 +418,7 @@ struct SmallMulti {
     const float* weights;         // [n_acq][N] or null
     float* losses;                // [n_steps] or null
     unsigned* sync;               // [0] arrivals (zeroed by the host before the launch), [1] error word
+    unsigned spin_limit;          // polls a block waits at a grid barrier before it raises the error word
     long long w_off[SMALL_MAX_LAYERS + 1], b_off[SMALL_MAX_LAYERS + 1];
     long long P;
     int N, F, S, n_acq, first_acq, n_steps, nblocks, tpp;
@@ -457,7 +459,7 @@ __device__ __forceinline__ float load_shared(const float* p) {
 // Arrive + wait on a monotonically increasing counter (`target` = barrier ordinal x blocks).  Returns false when the
 // launch has to be abandoned (poll limit or another block's error word); the value is uniform over the block.
 template <bool ACQUIRE>
-__device__ __forceinline__ bool small_grid_barrier(unsigned* sync, unsigned target, int* flag) {
+__device__ __forceinline__ bool small_grid_barrier(unsigned* sync, unsigned target, int* flag, unsigned spin_limit) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's write-through stores have reached memory
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -466,7 +468,7 @@ __device__ __forceinline__ bool small_grid_barrier(unsigned* sync, unsigned targ
         int ok = 1;
         while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++polls > SM_SPIN_LIMIT || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (++polls > spin_limit || __hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -872,7 +874,7 @@ __global__ void __launch_bounds__(SM_THREADS) siren_small_multi_kernel(const Sma
         flush_grads();                                                   // layer 0's
         // ------------------------------- gradient reduction + Adam over the whole grid -----------------------------
         SM_STAMP(4);
-        if (!small_grid_barrier<false>(p.sync, ++barrier_no * (unsigned)nblk, &bar_flag)) return;
+        if (!small_grid_barrier<false>(p.sync, ++barrier_no * (unsigned)nblk, &bar_flag, p.spin_limit)) return;
         SM_STAMP(5);
         {
             const float step_size = p.step_size[step], bc2_sqrt = p.bc2_sqrt[step];
@@ -931,21 +933,47 @@ __global__ void __launch_bounds__(SM_THREADS) siren_small_multi_kernel(const Sma
         }
         if (step + 1 < p.n_steps) prefetch_inputs(step + 1);
         SM_STAMP(6);
-        if (!small_grid_barrier<false>(p.sync, ++barrier_no * (unsigned)nblk, &bar_flag)) return;
+        if (!small_grid_barrier<false>(p.sync, ++barrier_no * (unsigned)nblk, &bar_flag, p.spin_limit)) return;
         SM_STAMP(7);
     }
 }
 
-int g_small_rows = 0;   // rows per block of the persistent kernel: 0 = choose (32 when that still fits one block per CU), 32, 64
+tune_int g_small_spin_limit{0};   // inr_debug_set(17, n): poll limit of the grid barrier (0 = SM_SPIN_LIMIT); tests force the abandon path with 1
+tune_int g_small_rows{0};   // rows per block of the persistent kernel: 0 = choose (32 when that still fits one block per CU), 32, 64
+
+// Cooperative launches need every block co-resident.  The limit comes from the device (CU count x blocks of the chosen
+// instantiation that fit a CU -- one, at ~140 KB of static LDS), not from a constant: a partitioned (CPX / DPX) or CU-masked
+// device has fewer than 256 CUs.  Cached per process; without a device (build container) the MI355X figure stands in.
+template <int H, int ROWS>
+static int multi_capacity_of() {
+    int dev = 0, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 256;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, siren_small_multi_kernel<H, ROWS>, SM_THREADS, 0) != hipSuccess ||
+        per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    return prop.multiProcessorCount * per_cu;
+}
+static int multi_capacity(int H, int rows) {
+    static int cap[3] = {0, 0, 0};
+    const int k = (H == 32) ? 0 : (rows == 32 ? 1 : 2);
+    if (!cap[k]) cap[k] = (k == 0) ? multi_capacity_of<32, 64>() : (k == 1) ? multi_capacity_of<64, 32>() : multi_capacity_of<64, 64>();
+    return cap[k];
+}
 
 static int multi_rows(const inr_siren_desc_t* d, int64_t n) {
     if (d->hidden_features != 64) return 64;
     if (g_small_rows == 64) return 64;
-    return (n + 31) / 32 <= 256 ? 32 : 64;
+    return (n + 31) / 32 <= multi_capacity(64, 32) ? 32 : 64;
 }
 
 bool small_multi_ok(const inr_siren_desc_t* d, int64_t n) {
-    return small_path_ok(d, n) && (n + 63) / 64 <= 256;      // one block per CU: all blocks co-resident
+    return small_path_ok(d, n) && (n + 63) / 64 <= multi_capacity(d->hidden_features, 64);      // all blocks co-resident
 }
 
 static inline int multi_blocks(const inr_siren_desc_t* d, int64_t n) {
@@ -985,6 +1013,8 @@ int small_fit_multi(const inr_siren_desc_t* d, const long long* w_off, const lon
     p.inv_count = (float)(1.0 / (double)n);
     p.one_minus_b1 = (float)(1.0 - b1); p.b2 = (float)b2; p.one_minus_b2 = (float)(1.0 - b2); p.eps = (float)eps;
     p.stamps = g_stamps;
+    const int lim = g_small_spin_limit;
+    p.spin_limit = lim > 0 ? (unsigned)lim : SM_SPIN_LIMIT;
     for (int done = 0; done < n_steps; done += SM_MAX_STEPS) {
         const int k = n_steps - done < SM_MAX_STEPS ? n_steps - done : SM_MAX_STEPS;
         p.n_steps = k;
@@ -996,13 +1026,28 @@ int small_fit_multi(const inr_siren_desc_t* d, const long long* w_off, const lon
             p.bc2_sqrt[i] = (float)sqrt(1.0 - pow(b2, t));
         }
         ProfScope ps(KC_OTHER, st);
-        INR_HIP(hipMemsetAsync(p.sync, 0, 2 * sizeof(unsigned), st));
+        INR_HIP(hipMemsetAsync(p.sync, 0, (done == 0 ? 2 : 1) * sizeof(unsigned), st));   // the error word is sticky within a call
         void* args[] = {(void*)&p};
         const void* fn = (H == 32) ? (const void*)siren_small_multi_kernel<32, 64>
                          : (rows == 32) ? (const void*)siren_small_multi_kernel<64, 32>
                                         : (const void*)siren_small_multi_kernel<64, 64>;
-        INR_HIP(hipLaunchCooperativeKernel(fn, dim3(nb), dim3(SM_THREADS), args, 0, st));   // refused unless co-resident
+        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(nb), dim3(SM_THREADS), args, 0, st);   // refused unless co-resident
+        if (e == hipErrorCooperativeLaunchTooLarge && done == 0) {
+            (void)hipGetLastError();
+            return INR_E_FALLBACK;   // (caller: the two-launch step serves this device)
+        }
+        INR_HIP(e);
+        count_launch(LF_SMALL_MULTI);
     }
+    // A grid barrier that ran into its poll limit makes every block leave mid-step: parameters, Adam moments and losses are
+    // then partly updated.  That must not pass for success, so this path reads the error word back -- the one place where an
+    // entry point waits for the stream (cooperative launches cannot be captured into a graph anyway; include/inrhip.h).
+    unsigned err = 0;
+    INR_HIP(hipMemcpyAsync(&err, p.sync + 1, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    INR_HIP(hipStreamSynchronize(st));
+    INR_REQUIRE(err == 0, INR_E_TIMEOUT,
+                "small-network persistent kernel: a grid barrier exceeded its poll limit and the launch was abandoned; "
+                "params / m / v / losses of this call are partly updated and must be discarded");
     return 0;
 }
 

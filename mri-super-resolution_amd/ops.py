@@ -457,6 +457,48 @@ def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_tot
     return workspace
 
 
+# ---- diagnostics ------------------------------------------------------------------------------------------
+LAUNCH_FAMILIES = ("hp_pkd", "hp_pkc", "hp_tile", "hp_rc", "h3", "f32_pipe16", "f32_pipe", "f32_generic", "small_multi",
+                   "small_step", "hp_narrow")   # INR_LF_* of include/inrhip.h, in order
+
+
+def launch_counts() -> dict:
+    """Launches each kernel family has received since the last ``launch_counts_reset()`` (process-global)."""
+    out = {}
+    for i, name in enumerate(LAUNCH_FAMILIES):
+        n = C.c_int64(0)
+        check(lib().inr_launch_count(i, C.byref(n)), "inr_launch_count")
+        out[name] = int(n.value)
+    return out
+
+
+def launch_counts_reset():
+    check(lib().inr_launch_counts_reset())
+
+
+def debug_get(key: int) -> int:
+    v = C.c_int(0)
+    check(lib().inr_debug_get(int(key), C.byref(v)), "inr_debug_get")
+    return int(v.value)
+
+
+class debug_switch:
+    """``with debug_switch(key, value): ...`` -- a diagnostic switch (process-global, include/inrhip.h) set for the block
+    and put back to what it was, also when the block raises."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.value = int(key), int(value)
+
+    def __enter__(self):
+        self.old = debug_get(self.key)
+        check(lib().inr_debug_set(self.key, self.value), "inr_debug_set")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().inr_debug_set(self.key, self.old), "inr_debug_set")
+        return False
+
+
 # ---- measurement hooks ------------------------------------------------------------------------------------
 def prof_enable(on: bool):
     check(lib().inr_prof_enable(1 if on else 0))

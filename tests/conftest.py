@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 
 
+@pytest.fixture(autouse=True)
+def _restore_debug_switches():
+    """The diagnostic switches behind inr_debug_set are process-global: whatever a test flipped (even one that died between
+    set and reset) is back at its default before the next test starts."""
+    yield
+    from mri_super_resolution_amd import _lib
+    if _lib._LIB is not None:
+        _lib._LIB.inr_debug_reset()
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

@@ -130,3 +130,27 @@ def test_compat_modules_import():
     a = INRmodel.Siren(8, 16, 1, 1)
     assert a.flavor == "INRmodel" and list(dict(a.named_parameters()))[0] == "final_linear.weight"
     assert nn_mri.Siren(2, 8, 1, 1).return_coords is True
+
+
+def test_debug_switches_are_validated_readable_and_resettable():
+    """The diagnostic switches: unknown keys and out-of-range values are refused, a value can be read back, and one call
+    restores every default (what tests/conftest.py does after each test)."""
+    lib = _lib.lib()
+    v = ctypes.c_int(-7)
+    assert lib.inr_debug_get(10, ctypes.byref(v)) == 0 and v.value == 2
+    assert lib.inr_debug_set(10, 1) == 0
+    assert lib.inr_debug_get(10, ctypes.byref(v)) == 0 and v.value == 1
+    assert lib.inr_debug_set(10, 3) == _lib.INR_E_INVALID and b"takes 0 .. 2" in lib.inr_last_error()
+    assert lib.inr_debug_set(4, 1) == _lib.INR_E_INVALID and b"unknown key" in lib.inr_last_error()
+    assert lib.inr_debug_get(99, ctypes.byref(v)) == _lib.INR_E_INVALID
+    for key, val in ((0, 1), (3, 0), (7, 0), (12, 0), (14, 5), (16, 0), (17, 1), (18, 0)):
+        assert lib.inr_debug_set(key, val) == 0, key
+    assert lib.inr_debug_reset() == 0
+    for key, default in ((0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (6, 1), (7, 1), (10, 2), (11, 0), (12, 1), (13, 0), (14, 2),
+                         (15, 8), (16, 1), (17, 0), (18, 1)):
+        assert lib.inr_debug_get(key, ctypes.byref(v)) == 0 and v.value == default, (key, v.value)
+    n = ctypes.c_int64(-1)
+    assert lib.inr_launch_counts_reset() == 0
+    for fam in range(_lib.INR_LF_COUNT):
+        assert lib.inr_launch_count(fam, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.inr_launch_count(_lib.INR_LF_COUNT, ctypes.byref(n)) == _lib.INR_E_INVALID

@@ -1,0 +1,329 @@
+"""-m gpu: every kernel family the pre-split (HL32) path can dispatch to, against a float64 oracle.
+
+`hp_eligible` (csrc/api.hip) admits hidden in {128, 256, 512, 1024}, any in_features / hidden multiple of 32, up to 8 sine
+layers, one output.  Behind it sit four GEMM families (csrc/gemm_hp.inc): `pkd` (persistent, deferred epilogue: K = 256 /
+512), `pkc` (persistent, epilogue in line: every other K >= 96), the one-block-per-tile kernel (K < 96, and everything when
+the persistent grid is switched off) and the row-contraction kernel of the parameter gradient; on top `pkn`, the 64-row
+tiles a launch with few row tiles takes.  Each case below asserts WHICH families ran (inr_launch_count) so that a silent
+fall-back to the fp32 kernels cannot pass, then checks forward (T1), loss and every gradient tensor (T2) against the torch
+port evaluated in float64 (same op sequence as SRDWI.py:58-59,86-91 / superresDWI.py:135-137).
+
+Second half: the a-priori scale bound of the backward operands (`HpScale`: a bound that is too tight overflows fp16
+silently, one that is too loose loses low bits) under adversarial magnitudes ON THIS PATH -- targets / weights from 1e-30 to
+1e3, one row 1e6 above the rest, a network built so that the bound is attained, and the weights at the end of a full
+2,500-step fit, where the gradient is a small difference of large terms.  Criterion there: finite, and as close to float64
+as the exact-fp32 (f32-input MFMA) kernels are, up to a small factor.
+"""
+import numpy as np
+import pytest
+import torch
+
+import mri_super_resolution_amd as inr
+from mri_super_resolution_amd import ops
+from oracle import inr_oracle as O
+from oracle import torch_port as P
+
+pytestmark = pytest.mark.gpu
+
+T1 = 1e-5
+T2 = 1e-5
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def make_pair(fin, hidden, layers, seed, dtype=torch.float64):
+    """Our module and the port with the same draws; the port converted to `dtype` for the oracle side."""
+    torch.manual_seed(seed)
+    net = inr.Siren(fin, hidden, layers, 1)
+    torch.manual_seed(seed)
+    ref = P.PortSiren(fin, hidden, layers, 1)
+    return net, ref.to(dtype)
+
+
+def oracle_loss_grads(ref, x, t, w):
+    """float64 loss and gradients in network order (W_0, b_0, ..., W_head, b_head)."""
+    for p in ref.parameters():
+        p.grad = None
+    out = ref(x.double())
+    sq = (out - t.double().reshape(-1, 1)) ** 2
+    loss = (sq if w is None else w.double().reshape(-1, 1) * sq).mean()
+    loss.backward()
+    mods = [m.linear if isinstance(m, P.PortSine) else m for m in ref.net]
+    return loss.item(), [g for m in mods for g in (m.weight.grad.numpy(), m.bias.grad.numpy())], out.detach().numpy()
+
+
+def fused_loss_grads(net, x, t, w):
+    desc, flat = inr.flat_parameters(net)
+    grads = torch.zeros_like(flat)
+    loss = torch.zeros(1, device="cuda")
+    ops.siren_loss_grad(desc, flat, grads, x, t, w, 0, loss)
+    _, offsets = ops.siren_param_layout(desc)
+    out = []
+    for (w_off, b_off), pw, pb in zip(offsets, net.layer_parameters()[0::2], net.layer_parameters()[1::2]):
+        out.append(host(grads[w_off:w_off + pw.numel()]).reshape(pw.shape))
+        out.append(host(grads[b_off:b_off + pb.numel()]))
+    return loss.item(), out, host(ops.siren_forward(desc, flat, x))
+
+
+NARROW_KERNEL = False    # csrc/gemm_hp.inc: gemm_hp_pkn_kernel (64-row tiles for launches with few row tiles)
+
+
+def kc_family(K, deferred_ok, n, width, persistent=2, narrow=1):
+    """The launcher rule of hp_sine_forward / hp_input_grad (csrc/gemm_f32.hip) for one K-contiguous GEMM of `n` rows and
+    `width` output columns, spelled out a second time on purpose: a change of the dispatch has to be made in both places."""
+    few_tiles = ((n + 127) // 128) * ((width + 255) // 256) < 2 * 256
+    if NARROW_KERNEL and narrow and persistent and few_tiles and K >= 96:
+        return "hp_narrow"
+    if persistent == 2 and deferred_ok:
+        return "hp_pkd"
+    if persistent and K >= 96:
+        return "hp_pkc"
+    return "hp_tile"
+
+
+def expected_families(fin, hidden, layers, n, backward=True, persistent=2, narrow=1):
+    """family -> launches of ONE inr_siren_loss_grad (backward=True) or inr_siren_forward call."""
+    S = layers + 1
+    fam = {}
+    for l in range(S):
+        K = fin if l == 0 else hidden
+        name = kc_family(K, K in (256, 512), n, hidden, persistent, narrow)
+        fam[name] = fam.get(name, 0) + 1
+    if backward:
+        for _ in range(S - 1):
+            name = kc_family(hidden, hidden == 512, n, hidden, persistent, narrow)
+            fam[name] = fam.get(name, 0) + 1
+        fam["hp_rc"] = S
+    return fam
+
+
+def check_families(counts, *wants):
+    total = {}
+    for w in wants:
+        for k, v in w.items():
+            total[k] = total.get(k, 0) + v
+    for name in ops.LAUNCH_FAMILIES:
+        if not name.startswith("small"):
+            assert counts[name] == total.get(name, 0), (name, counts, total)
+
+
+# (in_features, hidden, hidden_layers, rows): every K class of the three KC families, the widest and the narrowest hidden
+# size, no hidden layer at all, the deepest network the path takes (8 sine layers), ragged row counts
+SHAPES = [
+    (32, 128, 0, 777),
+    (64, 128, 2, 1000),
+    (96, 256, 1, 1531),
+    (256, 256, 5, 2049),
+    (512, 256, 3, 513),
+    (32, 512, 7, 700),
+    (512, 512, 0, 300),
+    (160, 512, 2, 4099),
+    (64, 1024, 1, 515),
+    (1024, 1024, 2, 260),
+    (128, 128, 3, 70000),
+    (256, 512, 3, 66000),
+]
+
+
+@pytest.mark.parametrize("narrow", [1, 0])
+@pytest.mark.parametrize("fin,hidden,layers,n", SHAPES)
+def test_every_eligible_shape_class_vs_float64(fin, hidden, layers, n, narrow):
+    net, ref = make_pair(fin, hidden, layers, seed=fin + hidden + layers)
+    net.cuda()
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, fin, generator=g) * 2 - 1
+    t = torch.rand(n, generator=g)
+    w = (torch.rand(n, generator=g) > 0.25).float() * (0.5 + torch.rand(n, generator=g))
+    want_loss, want_g, want_y = oracle_loss_grads(ref, x, t, w)
+    with ops.debug_switch(18, narrow):
+        ops.launch_counts_reset()
+        loss, got_g, got_y = fused_loss_grads(net, x.cuda(), t.cuda(), w.cuda())
+        counts = ops.launch_counts()
+    check_families(counts, expected_families(fin, hidden, layers, n, True, narrow=narrow),
+                   expected_families(fin, hidden, layers, n, False, narrow=narrow))     # loss_grad + the forward call
+    assert O.rel_l2(got_y, want_y) < T1
+    assert abs(loss - want_loss) <= T2 * want_loss
+    for k, (a, b) in enumerate(zip(got_g, want_g)):
+        assert O.rel_l2(a, b) < T2, (k, O.rel_l2(a, b))
+
+
+@pytest.mark.parametrize("persistent,zhead", [(0, 1), (1, 1), (2, 0)])
+@pytest.mark.parametrize("fin,hidden,layers,n", [(256, 512, 3, 3000), (64, 256, 2, 1100), (512, 1024, 1, 400)])
+def test_fallback_families_of_the_persistent_grid(fin, hidden, layers, n, persistent, zhead):
+    """inr_debug_set(10, 0 / 1): the one-block-per-tile kernel and the in-line-epilogue persistent kernel serve EVERY K;
+    key 16 = 0: the last sine layer stashes act + omega cos instead of z.  Same tolerances."""
+    net, ref = make_pair(fin, hidden, layers, seed=7 * persistent + zhead)
+    net.cuda()
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, fin, generator=g) * 2 - 1
+    t = torch.rand(n, generator=g) * 2 - 1
+    want_loss, want_g, want_y = oracle_loss_grads(ref, x, t, None)
+    with ops.debug_switch(10, persistent), ops.debug_switch(16, zhead), ops.debug_switch(18, 0):
+        ops.launch_counts_reset()
+        loss, got_g, got_y = fused_loss_grads(net, x.cuda(), t.cuda(), None)
+        counts = ops.launch_counts()
+    if persistent == 0:
+        assert counts["hp_tile"] == 3 * (layers + 1) - 1 and counts["hp_pkd"] == counts["hp_pkc"] == 0, counts
+    elif persistent == 1:
+        assert counts["hp_pkd"] == 0 and counts["hp_pkc"] + counts["hp_tile"] == 3 * (layers + 1) - 1, counts
+    assert counts["hp_rc"] == layers + 1 and counts["h3"] == counts["f32_pipe16"] == counts["f32_generic"] == 0, counts
+    assert O.rel_l2(got_y, want_y) < T1
+    assert abs(loss - want_loss) <= T2 * want_loss
+    for k, (a, b) in enumerate(zip(got_g, want_g)):
+        assert O.rel_l2(a, b) < T2, (k, O.rel_l2(a, b))
+
+
+# ------------------------------------------------------------------ the scale bound under adversarial magnitudes ---------
+def grads_on(net, x, t, w, exact_fp32):
+    with ops.debug_switch(3, 0 if exact_fp32 else 1):
+        ops.launch_counts_reset()
+        out = fused_loss_grads(net, x, t, w)
+        c = ops.launch_counts()
+    if exact_fp32:
+        assert c["hp_pkd"] + c["hp_pkc"] + c["hp_tile"] + c["hp_rc"] + c["hp_narrow"] + c["h3"] == 0 and c["f32_pipe16"] > 0, c
+    else:
+        assert c["hp_rc"] > 0 and c["f32_pipe16"] + c["f32_generic"] + c["h3"] == 0, c
+    return out
+
+
+def assert_fp32_class(net, ref, x, t, w, factor=4.0, floor=3e-7):
+    """Gradients of the HL32 path are finite and within `factor` x the exact-fp32 kernels' own distance from float64."""
+    want_loss, want_g, _ = oracle_loss_grads(ref, x, t, w)
+    xd, td, wd = x.cuda(), t.cuda(), None if w is None else w.cuda()
+    loss_h, g_h, _ = grads_on(net, xd, td, wd, exact_fp32=False)
+    loss_f, g_f, _ = grads_on(net, xd, td, wd, exact_fp32=True)
+    assert np.isfinite(loss_h) and abs(loss_h - want_loss) <= 1e-5 * abs(want_loss) + 1e-37
+    worst = 0.0
+    for k, (a, f, b) in enumerate(zip(g_h, g_f, want_g)):
+        assert np.isfinite(a).all(), k
+        if np.linalg.norm(b) == 0.0:
+            assert not a.any(), k
+            continue
+        eh, ef = O.rel_l2(a, b), O.rel_l2(f, b)
+        assert eh <= factor * ef + floor, (k, eh, ef)
+        worst = max(worst, eh)
+    return worst
+
+
+@pytest.mark.parametrize("t_scale", [1e-30, 1e-12, 1.0, 1e3])
+@pytest.mark.parametrize("fin,hidden,layers", [(256, 512, 3), (64, 256, 2), (128, 1024, 1)])
+def test_target_magnitudes(fin, hidden, layers, t_scale):
+    net, ref = make_pair(fin, hidden, layers, seed=3)
+    net.cuda()
+    g = torch.Generator().manual_seed(17)
+    n = 2500
+    x = torch.rand(n, fin, generator=g) * 2 - 1
+    t = (torch.rand(n, generator=g) * 2 - 1) * t_scale
+    assert_fp32_class(net, ref, x, t, None)
+
+
+@pytest.mark.parametrize("head_scale,hidden_scale,first_scale", [(1e-6, 1.0, 1.0), (1e2, 1.0, 1.0), (1.0, 1e-4, 1.0),
+                                                                  (1.0, 3.0, 1.0), (1.0, 1.0, 1e-5), (1e-20, 1e-3, 20.0)])
+def test_weight_magnitudes(head_scale, hidden_scale, first_scale):
+    net, ref = make_pair(256, 512, 3, seed=5)
+    with torch.no_grad():
+        for m_ours, m_ref in ((net.final_linear, ref.final_linear),):
+            m_ours.weight.mul_(head_scale)
+            m_ref.weight.mul_(head_scale)
+        for l in range(4):
+            s = first_scale if l == 0 else hidden_scale
+            net.net[l].linear.weight.mul_(s)
+            ref.net[l].linear.weight.mul_(s)
+    net.cuda()
+    g = torch.Generator().manual_seed(23)
+    n = 3000
+    x = torch.rand(n, 256, generator=g) * 2 - 1
+    t = torch.rand(n, generator=g)
+    w = torch.rand(n, generator=g)
+    assert_fp32_class(net, ref, x, t, w)
+
+
+def test_one_row_a_million_above_the_rest():
+    """A weight image (master.py:143-147) with one voxel 1e6 above the others, and the same for the targets: the tensor scale
+    follows the maximum; norm-wise nothing is lost, and the small rows still carry their gradient."""
+    net, ref = make_pair(256, 512, 2, seed=11)
+    net.cuda()
+    g = torch.Generator().manual_seed(29)
+    n = 2048
+    x = torch.rand(n, 256, generator=g) * 2 - 1
+    t = torch.rand(n, generator=g)
+    w = torch.rand(n, generator=g) * 1e-3
+    w[77] = 1e3
+    assert_fp32_class(net, ref, x, t, w)
+    t2 = t.clone()
+    t2[5] = 1e6
+    assert_fp32_class(net, ref, x, t2, None)
+    # without the outlier row the remaining gradient is still right (elementwise health of rows far below the maximum)
+    w0 = w.clone()
+    w0[77] = 0.0
+    assert_fp32_class(net, ref, x, t, w0)
+
+
+def test_bound_attained_constant_sign_network():
+    """The bound of dz_l is max|dz_{l+1}| x max_j sum_k |W_{l+1}[k][j]| x omega.  It is ATTAINED when every weight of a layer
+    has the same sign and magnitude, every pre-activation is ~0 (cos = 1) and dz_{l+1} is constant along a row -- which this
+    network does on purpose: a bound computed a hair too small would push the largest element past fp16's range (inf / NaN
+    in the gradients); the 1.001 safety factors of HpScale are what this pins."""
+    fin, hidden, layers, n = 256, 512, 3, 1500
+    net, ref = make_pair(fin, hidden, layers, seed=1)
+    with torch.no_grad():
+        for m in (net, ref):
+            for l in range(layers + 1):
+                lin = m.net[l].linear
+                lin.weight.fill_(1e-7 if l else 1e-8)
+                lin.bias.zero_()
+            m.final_linear.weight.fill_(0.01)
+            m.final_linear.bias.zero_()
+    net.cuda()
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(n, fin, generator=g) * 2 - 1
+    for t_val in (1.0, -1.0, 1e-6, 250.0):
+        t = torch.full((n,), t_val)
+        assert_fp32_class(net, ref, x, t, None, factor=6.0)
+
+
+def test_zero_residual_and_zero_weight_image():
+    net, ref = make_pair(64, 128, 1, seed=2)
+    net.cuda()
+    x = torch.rand(500, 64) * 2 - 1
+    desc, flat = inr.flat_parameters(net)
+    y = ops.siren_forward(desc, flat, x.cuda()).reshape(-1)
+    loss, grads, _ = fused_loss_grads(net, x.cuda(), y.contiguous(), None)
+    assert loss == 0.0 and all(not g.any() for g in grads)
+    loss, grads, _ = fused_loss_grads(net, x.cuda(), torch.rand(500).cuda(), torch.zeros(500).cuda())
+    assert loss == 0.0 and all(np.isfinite(g).all() and not g.any() for g in grads)
+
+
+def test_late_training_state(golden):
+    """The weights after the full 2,500-step config-1 fit (superresDWI.py:132-138; loss ~1e-6: the gradient is a small
+    difference of large terms and the head's a-priori bound is ~2^11 above the actual residuals): gradients on the HL32 path
+    against float64 next to the exact-fp32 kernels, then 20 more steps staying on the exact-fp32 trajectory."""
+    d = golden("dataset_ff.npz")
+    lr_img = golden("pat07_slice11.npz")["lr"]
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1).cuda()
+    B = torch.from_numpy(d["B2"]).cuda()
+    x = inr.input_mapping(inr.get_mgrid((64, 64)), B)
+    t = torch.from_numpy(lr_img.astype(np.float32).reshape(-1)).cuda()
+    fitter = inr.SirenFitter(net, lr=1e-4)
+    losses = host(fitter.step(x, t, 2500))
+    assert np.median(losses[-100:]) < 2e-5
+    # float64 twin of the fitted network
+    ref = P.PortSiren(256, 512, 3, 1).double()
+    ref.load_state_dict({k: v.detach().cpu().double() for k, v in net.state_dict().items()}, strict=False)
+    twin = inr.Siren(256, 512, 3, 1)
+    twin.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=False)
+    twin.cuda()
+    worst = assert_fp32_class(twin, ref, x.cpu(), t.cpu(), None, factor=4.0, floor=1e-6)
+    assert worst < 1e-3            # (cancellation: float32 itself sits at ~1e-5 .. 1e-4 here)
+    # the next 20 steps on both arithmetic paths from the same state (parameters + Adam moments)
+    state = (fitter.flat.clone(), fitter.m.clone(), fitter.v.clone(), fitter.step_count)
+    runs = {}
+    for exact in (False, True):
+        fitter.flat.copy_(state[0]); fitter.m.copy_(state[1]); fitter.v.copy_(state[2]); fitter.step_count = state[3]
+        with ops.debug_switch(3, 0 if exact else 1):
+            runs[exact] = (host(fitter.step(x, t, 20)).copy(), host(fitter.flat).copy())
+    assert np.isfinite(runs[False][0]).all()
+    assert O.rel_l2(runs[False][1], runs[True][1]) < 1e-4

@@ -603,3 +603,97 @@ def test_small_fused_step_equals_layerwise_path(n, fin, hidden, layers):
     assert np.allclose(out[0][0], out[1][0], rtol=2e-5)
     assert O.rel_l2(out[0][2], out[1][2]) < 2e-5            # gradients of the last step
     assert O.rel_l2(out[0][1], out[1][1]) < 2e-5            # parameters after 8 Adam steps
+
+
+# ------------------------------------------------------------------ the persistent kernel against the reference fixture ---
+@pytest.mark.parametrize("mode", ["multi", "multi_cycle3", "two_launch"])
+def test_small_net_kernels_vs_reference_fixture(golden, mode):
+    """`siren64_2d.npz` holds the REAL reference's (SRDWI.Siren(2,64,6,1), weighted MSE, torch Adam 3e-4) 50-step trajectory
+    on 3,600 rows (oracle/gen_golden.py).  The persistent cooperative kernel -- what master.py's 24,000-step fits run on --
+    is compared with it DIRECTLY: through inr_siren_fit (one acquisition), through inr_siren_fit_cycle with the same image
+    repeated as three acquisitions (the acquisition pointer moves every step, the data does not), and, for completeness, the
+    two-launch step kernels.  The launch counters say which kernel ran."""
+    s = golden("siren64_2d.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1).cuda()
+    x, t, w = dev(s["coords"]), dev(s["target"]), dev(s["weight"])
+    f = inr.SirenFitter(net, lr=3e-4)
+    ops.launch_counts_reset()
+    losses, snaps = [], {}
+    with ops.debug_switch(12, 0 if mode == "two_launch" else 1):
+        done = 0
+        for upto in (1, 10, 50):
+            k = upto - done
+            if mode == "multi_cycle3":
+                tg = t.reshape(1, -1).repeat(3, 1).contiguous()
+                wt = w.reshape(1, -1).repeat(3, 1).contiguous()
+                losses.append(host(f.step_cycle(x, tg, k, wt, first_acq=done % 3)))
+            else:
+                losses.append(host(f.step(x, t, n_steps=k, weight=w)))
+            done = upto
+            snaps[upto] = {n: host(p).copy() for n, p in net.named_parameters()}
+            snaps[upto]["recon"] = host(inr.reconstruct(net, (180, 180), None, clamp_min=None))
+    c = ops.launch_counts()
+    if mode == "two_launch":
+        assert c["small_step"] == 50 and c["small_multi"] == 0, c
+    else:
+        assert c["small_multi"] == 3 and c["small_step"] == 0, c
+    assert np.allclose(np.concatenate(losses), s["losses"], rtol=2e-4)
+    for upto in (1, 10, 50):
+        for n, _ in net.named_parameters():
+            assert O.rel_l2(snaps[upto][n], s[f"p{upto}/{n}"]) < T3, (upto, n)
+        assert O.rel_l2(snaps[upto]["recon"], s[f"recon180_{upto}"]) < T3, upto
+
+
+def test_small_net_abandoned_launch_is_reported(golden):
+    """The persistent kernel's grid barrier has an exit (poll limit -> error word -> every block leaves).  A launch that took
+    it leaves parameters and Adam moments partly updated: the entry point must say so (INR_E_TIMEOUT), not return 0.
+    inr_debug_set(17, 1) makes every barrier with more than one block give up at once."""
+    from mri_super_resolution_amd._lib import InrHipError
+    s = golden("siren64_2d.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(2, 64, 6, 1).cuda()
+    x, t, w = dev(s["coords"]), dev(s["target"]), dev(s["weight"])
+    f = inr.SirenFitter(net, lr=3e-4)
+    with ops.debug_switch(17, 1):
+        with pytest.raises(InrHipError, match="status -4.*abandoned"):
+            f.step(x, t, n_steps=70, weight=w)          # (two launches: the second one meets the sticky error word)
+    torch.cuda.synchronize()
+    # the library is healthy afterwards: a fresh fit on the same data follows the fixture
+    torch.manual_seed(0)
+    net2 = inr.Siren(2, 64, 6, 1).cuda()
+    f2 = inr.SirenFitter(net2, lr=3e-4)
+    assert np.allclose(host(f2.step(x, t, n_steps=10, weight=w)), s["losses"][:10], rtol=2e-4)
+
+
+def test_image_fitting_set_pil_branch():
+    """nn_mri.py:174-203 (the 2-D dataset of master.py:122-125): a list of square PIL images -> `.orig` (the arrays as
+    they are), `.mean` (their average), `.shape` (PIL's size tuple), pixels = Normalize(0.5, 0.5)(ToTensor(img)) = 2 x - 1
+    flattened row-major, where torchvision's ToTensor divides 8-bit images by 255 and only casts mode 'F' / 'I';
+    coords = get_mgrid(side, 2).  torchvision is absent from this image (and nn_mri imports SimpleITK), so this branch is
+    pinned by the documented semantics of those two transforms, not by a run of the reference."""
+    from PIL import Image
+    rng = np.random.default_rng(4)
+    side = 24
+    arrs_f = [rng.random((side, side)).astype(np.float32) * 3.0 for _ in range(3)]
+    ds = inr.ImageFitting_set([Image.fromarray(a) for a in arrs_f])
+    assert len(ds) == 3 and ds.shape == (side, side)
+    assert ds.orig.shape == (3, side, side) and np.array_equal(ds.orig, np.stack(arrs_f).astype(np.float64))
+    assert np.allclose(ds.mean, np.mean(np.stack(arrs_f).astype(np.float64), axis=0), rtol=0, atol=1e-15)
+    want = np.stack([(2.0 * a - 1.0).reshape(-1, 1) for a in arrs_f]).astype(np.float32)
+    assert np.array_equal(bits(host(ds.pixels)), bits(want))
+    grid = O.mgrid_square(side, 2)
+    assert tuple(ds.coords.shape) == (3, side * side, 2)
+    for k in range(3):
+        assert np.array_equal(bits(host(ds.coords[k])), bits(grid))
+    c, p = ds[1]
+    assert c is ds.coords and p is ds.pixels                       # nn_mri.py:199-200: the whole tensors, whatever idx
+    # 8-bit images: ToTensor scales by 1/255 before the normalisation; .orig keeps the raw counts
+    arr_u8 = rng.integers(0, 256, (side, side), dtype=np.uint8)
+    ds8 = inr.ImageFitting_set([Image.fromarray(arr_u8)])
+    assert np.array_equal(ds8.orig[0], arr_u8.astype(np.float64))
+    want8 = (2.0 * (arr_u8.astype(np.float32) / np.float32(255.0)) - 1.0).reshape(-1, 1)
+    assert np.allclose(host(ds8.pixels[0]), want8, rtol=0, atol=1.2e-7)
+    # a non-square or mixed-size list is refused (the reference would fail inside torch.empty / the copy)
+    with pytest.raises(ValueError):
+        inr.ImageFitting_set([Image.fromarray(arrs_f[0]), Image.fromarray(arrs_f[0][:20, :20].copy())])
