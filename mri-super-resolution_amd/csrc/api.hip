@@ -78,21 +78,24 @@ int param_grad_splits(int64_t n, int in_f, int out_f);
 // pre-split (HL32) path: gemm_hp.inc
 bool hp_head_ok(int hidden);
 int gemm_build_flags();
-int hp_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* amax,
-                    unsigned* wnorm, hipStream_t stream);
+size_t hp_prep_part_bytes();
+int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* slots,
+                   unsigned* part, float* head_bound, const float* head_W, const float* head_b, int hidden, const unsigned* tmax,
+                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream);
 int hp_convert(char* out, const float* x, long long rows, int cols, HpScale sc, hipStream_t stream);
 int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc, hipStream_t stream);
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
                     int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false);
 bool hp_z_stash_ok(int in_f);
 extern tune_int g_hp_zhead;
+int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
-                  float* colsum_slab, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so, hipStream_t stream);
+                  float* colsum_slab, int* colsum_rows, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so,
+                  hipStream_t stream);
+int64_t hp_head_blocks(int64_t n);
 int hp_param_grad_splits(int64_t n, int in_f, int out_f);
 int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
                         HpScale sa, HpScale sb, hipStream_t stream);
-int hp_head_bound(float* out, const float* W, const float* bias, int hidden, const unsigned* tmax, const unsigned* wtmax,
-                  float inv_count, float omega, hipStream_t stream);
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
                     float clamp_min, hipStream_t stream);
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
@@ -269,6 +272,7 @@ struct H3Ctx {
     bool on = false;
     _Float16* planes = nullptr;
     unsigned* slots = nullptr;
+    unsigned* part = nullptr;           // scratch of the per-step weight statistics (gemm_hp.inc)
     std::vector<long long> plane_off;   // halves, per sine layer
 };
 static bool h3_eligible(const Layout& L) {
@@ -280,13 +284,14 @@ static bool h3_eligible(const Layout& L) {
 static size_t h3_ctx_bytes(const Layout& L) {
     long long w = 0;
     for (int l = 0; l < L.n_sine; ++l) w += (long long)L.fan_in[l] * L.fan_out[l];
-    return round_up(256 + h3_planes_bytes(w), 256);
+    return round_up(256 + hp_prep_part_bytes() + h3_planes_bytes(w), 256);
 }
 static H3Ctx h3_make_ctx(const Layout& L, char* region) {
     H3Ctx c;
     c.on = true;
     c.slots = reinterpret_cast<unsigned*>(region);
-    c.planes = reinterpret_cast<_Float16*>(region + 256);
+    c.part = reinterpret_cast<unsigned*>(region + 256);
+    c.planes = reinterpret_cast<_Float16*>(region + 256 + hp_prep_part_bytes());
     long long off = 0;
     for (int l = 0; l < L.n_sine; ++l) {
         c.plane_off.push_back(off);
@@ -338,8 +343,9 @@ static H3Args h3_param_grad_args(const H3Ctx& c, int l) {
 
 
 // ---- pre-split (HL32) context: gemm_hp.inc ------------------------------------------------------------------------------
-// Shares the H3Ctx region: 256 bytes of slots, then 8 bytes per weight (HL32 [out][in], then HL32 [in][out] per layer).
-// slots: [l] max|W_l| bits, [8 + l] measured max|dz_l| bits, [16 + l] wnorm_l (float bits) -- all three zeroed every step;
+// Shares the H3Ctx region: 256 bytes of slots, the statistics scratch, then 8 bytes per weight (HL32 [out][in], then HL32
+// [in][out] per layer).
+// slots: [l] max|W_l| bits, [8 + l] measured max|dz_l| bits, [16 + l] wnorm_l (float bits) -- all three rebuilt every step;
 // [24] max|x| (floor 1), [25] max|target|, [26] max|weight| (per call); [27] bound of the head's dz (float, every step)
 static bool hp_eligible(const inr_siren_desc_t* d, const Layout& L) {
     if (!g_hp || !g_h3 || g_force_generic || !h3_eligible(L)) return false;
@@ -355,7 +361,15 @@ struct HpNet {
     HpScale act_scale(int l) const { return l == 0 ? x_scale() : HpScale{}; }   // input of sine layer l
     float* head_bound() const { return reinterpret_cast<float*>(c->slots + 27); }
 };
-static int hp_refresh_weights(const HpNet& net, const float* params, hipStream_t st) {
+// this step's weights as HL32 images + their scales; with `head` (fit steps) also the a-priori bound of the head's dz
+struct HpHeadBoundArgs {
+    const float* W;
+    const float* b;
+    const unsigned* tmax;
+    const unsigned* wtmax;
+    float inv_count, omega;
+};
+static int hp_refresh_weights(const HpNet& net, const float* params, hipStream_t st, const HpHeadBoundArgs* head = nullptr) {
     const Layout& L = *net.L;
     const float* W[8];
     int of[8], inf[8];
@@ -364,8 +378,10 @@ static int hp_refresh_weights(const HpNet& net, const float* params, hipStream_t
         of[l] = L.fan_out[l];
         inf[l] = L.fan_in[l];
     }
-    INR_HIP(hipMemsetAsync(net.c->slots, 0, sizeof(unsigned) * 24, st));
-    return hp_weight_split(W, of, inf, L.n_sine, reinterpret_cast<char*>(net.c->planes), net.c->slots, net.c->slots + 16, st);
+    return hp_weight_prep(W, of, inf, L.n_sine, reinterpret_cast<char*>(net.c->planes), net.c->slots, net.c->part,
+                          head ? net.head_bound() : nullptr, head ? head->W : nullptr, head ? head->b : nullptr,
+                          L.fan_in[L.n_sine], head ? head->tmax : nullptr, head ? head->wtmax : nullptr,
+                          head ? head->inv_count : 0.f, head ? head->omega : 0.f, st);
 }
 
 static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
@@ -714,6 +730,48 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
     return 0;
 }
 
+// ---- where the producers of the pre-split step leave their slab rows until launch_finalize sums them (common.h) ----------
+// Tensor order = flat parameter order: W_0, b_0, ..., W_{S-1}, b_{S-1}, W_head, b_head.  Offsets in floats from the slab region.
+struct HpSlabPlan {
+    struct Seg {
+        size_t slab, stage1;
+        long long len;
+        int max_rows;
+    };
+    std::vector<Seg> seg;       // 2 (S + 1)
+    size_t part_loss = 0;       // [head blocks]
+    size_t loss_sink = 0;       // where the loss goes when the caller does not want it
+    size_t total = 0;
+};
+static HpSlabPlan hp_slab_plan(const Layout& L, int64_t n) {
+    HpSlabPlan p;
+    const int S = L.n_sine, H = L.fan_in[S];
+    const int64_t hb = hp_head_blocks(n);
+    size_t off = 0;
+    auto add = [&](long long len, int rows) {
+        HpSlabPlan::Seg sg;
+        sg.len = len;
+        sg.max_rows = rows;
+        sg.slab = off;
+        off += round_up((size_t)rows * (size_t)len, 4);
+        sg.stage1 = off;
+        if (rows > FIN_TALL) off += round_up((size_t)((rows + FIN_GROUP - 1) / FIN_GROUP) * (size_t)len, 4);
+        p.seg.push_back(sg);
+    };
+    for (int l = 0; l < S; ++l) {
+        add((long long)L.fan_in[l] * L.fan_out[l], hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]));
+        add(L.fan_out[l], l == S - 1 ? (int)hb : hp_input_grad_max_rows(n));
+    }
+    add(H, (int)hb);     // W_head: the head step's slab_w
+    add(1, (int)hb);     // b_head: its per-block sums of g
+    p.part_loss = off;
+    off += round_up((size_t)hb, 4);
+    p.loss_sink = off;
+    off += 4;
+    p.total = off;
+    return p;
+}
+
 // workspace carve for the fit: acts (n_sine x n x H), dacts (n_sine x n x H), y, gy, scratch
 struct FitCarve {
     size_t act_b, out_b, scratch_b, total, h3_off, xhl_off;
@@ -729,6 +787,7 @@ static FitCarve fit_carve(const inr_siren_desc_t* d, const Layout& L, int64_t n)
     }
     const size_t mse = (size_t)mse_blocks((int64_t)n * d->out_features) + 1;
     if (mse > scratch) scratch = mse;
+    if (L.n_sine <= 8 && d->out_features == 1) scratch = max2(scratch, hp_slab_plan(L, n).total);   // deferred slabs of the HL32 step
     c.scratch_b = round_up(scratch * sizeof(float), 256);
     c.h3_off = 2 * (size_t)L.n_sine * c.act_b + 2 * c.out_b + c.scratch_b;
     c.xhl_off = c.h3_off + h3_ctx_bytes(L);
@@ -814,19 +873,33 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
 
 
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
-// dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound)
+// dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
+// here: every producer leaves its slab rows in `slabs` and `fin` describes them (the caller finishes with launch_finalize).
 static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
-                                   std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* scratch,
+                                   std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* slabs,
                                    const float* target, const float* weight, int64_t n, int64_t count_total, float* loss_dst,
-                                   hipStream_t st, const H3Ctx& ctx) {
+                                   hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin) {
     const int H = d->hidden_features, head = L.n_sine;
     const HpNet net{&ctx, &L};
-    if (int rc = hp_refresh_weights(net, params, st)) return rc;
+    const HpSlabPlan plan = hp_slab_plan(L, n);
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
     const float omega_last = (head - 1 == 0) ? d->first_omega : d->hidden_omega;
-    if (int rc = hp_head_bound(net.head_bound(), params + L.w_off[head], params + L.b_off[head], H, ctx.slots + 25,
-                               weight ? ctx.slots + 26 : nullptr, inv, omega_last, st))
-        return rc;
+    const HpHeadBoundArgs hb{params + L.w_off[head], params + L.b_off[head], ctx.slots + 25, weight ? ctx.slots + 26 : nullptr,
+                             inv, omega_last};
+    if (int rc = hp_refresh_weights(net, params, st, &hb)) return rc;
+    fin = FinalizeJob{};
+    fin.nseg = 2 * (head + 1);
+    for (int k = 0; k < fin.nseg; ++k) {
+        const int l = k >> 1;
+        fin.seg[k].slab = slabs + plan.seg[k].slab;
+        fin.seg[k].stage1 = slabs + plan.seg[k].stage1;
+        fin.seg[k].len = plan.seg[k].len;
+        fin.seg[k].dst = (k & 1) ? L.b_off[l] : L.w_off[l];
+        fin.seg[k].nslabs = 0;
+    }
+    fin.grads = grads;
+    fin.loss_out = loss_dst;
+    fin.loss_scale = inv;
     auto act_hl = [&](int l) -> const char* { return l == 0 ? xhl : reinterpret_cast<const char*>(act[l]); };
     // the output of the LAST sine layer feeds nothing but the head: that layer stashes z + b only (one fp32 matrix instead
     // of act + omega cos) and the head step forms sin / cos itself -- 2.1 GB less HBM traffic per step at N = 524,288
@@ -852,38 +925,32 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         return s;
     };
     {
-        const int64_t blocks = head_fused_blocks(n);
-        float* slab_b = scratch;
-        float* slab_w = scratch + blocks * H;
-        float* tmp = scratch + 2 * blocks * H;
-        float* part_loss = tmp + reduce_tmp_floats(blocks, H);
-        float* part_g = part_loss + blocks;
-        if (int rc = hp_head_step(reinterpret_cast<char*>(dact[head - 1]), slab_b, slab_w, part_loss, part_g, act_hl(head),
-                                  dact[head - 1], params + L.w_off[head], params + L.b_off[head], target, weight, n, H,
-                                  count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last))
+        const int blocks = (int)hp_head_blocks(n);
+        const int kb = 2 * (head - 1) + 1, kw = 2 * head, kg = 2 * head + 1;   // b_{S-1}, W_head, b_head
+        float* part_loss = slabs + plan.part_loss;
+        if (int rc = hp_head_step(reinterpret_cast<char*>(dact[head - 1]), const_cast<float*>(fin.seg[kb].slab),
+                                  const_cast<float*>(fin.seg[kw].slab), part_loss, const_cast<float*>(fin.seg[kg].slab),
+                                  act_hl(head), dact[head - 1], params + L.w_off[head], params + L.b_off[head], target, weight,
+                                  n, H, count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last))
             return rc;
-        if (int rc = launch_reduce_slabs(grads + L.b_off[head - 1], slab_b, (int)blocks, H, tmp, st)) return rc;
-        if (int rc = launch_reduce_slabs(grads + L.w_off[head], slab_w, (int)blocks, H, tmp, st)) return rc;
-        if (int rc = launch_finish_sum(loss_dst, part_loss, (int)blocks, inv, st)) return rc;
-        if (int rc = launch_finish_sum(grads + L.b_off[head], part_g, (int)blocks, 1.0f, st)) return rc;
+        fin.seg[kb].nslabs = fin.seg[kw].nslabs = fin.seg[kg].nslabs = blocks;
+        fin.part_loss = part_loss;
+        fin.nparts = blocks;
     }
     for (int l = L.n_sine - 1; l >= 0; --l) {
         const char* dz = reinterpret_cast<const char*>(dact[l]);
         const int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);
-        const int64_t len = (int64_t)L.fan_in[l] * L.fan_out[l];
-        if (int rc = hp_param_grad_slabs(scratch, splits, dz, act_hl(l), n, L.fan_in[l], L.fan_out[l], dz_scale(l),
-                                         net.act_scale(l), st))
+        if (int rc = hp_param_grad_slabs(const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), n, L.fan_in[l],
+                                         L.fan_out[l], dz_scale(l), net.act_scale(l), st))
             return rc;
-        if (int rc = launch_reduce_slabs(grads + L.w_off[l], scratch, splits, len, scratch + (int64_t)splits * len, st)) return rc;
+        fin.seg[2 * l].nslabs = splits;
         if (l > 0) {
-            const int rows = input_grad_colsum_rows(n);
+            int rows = 0;
             if (int rc = hp_input_grad(reinterpret_cast<char*>(dact[l - 1]), dz, net.wT_hl(l), dact[l - 1], n, L.fan_in[l],
-                                       L.fan_out[l], scratch, ctx.slots + 8 + l - 1, dz_scale(l), net.w_scale(l),
-                                       dz_scale(l - 1), st))
+                                       L.fan_out[l], const_cast<float*>(fin.seg[2 * (l - 1) + 1].slab), &rows,
+                                       ctx.slots + 8 + l - 1, dz_scale(l), net.w_scale(l), dz_scale(l - 1), st))
                 return rc;
-            if (int rc = launch_reduce_slabs(grads + L.b_off[l - 1], scratch, rows, L.fan_in[l],
-                                             scratch + (int64_t)rows * L.fan_in[l], st))
-                return rc;
+            fin.seg[2 * (l - 1) + 1].nslabs = rows;
         }
     }
     return 0;
@@ -975,6 +1042,7 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
         if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
     const bool hp = hp_eligible(desc, L);
+    if (hp) loss_sink = scratch + hp_slab_plan(L, n).loss_sink;   // (scratch[0] is a slab row the finalize launch still reads)
     char* xhl = base + c.xhl_off;
     if (hp && n_steps > 0) {
         if (int rc = hp_prepare_call(h3, L, xhl, x, targets, weights, n, desc->out_features, st, n_acq)) return rc;
@@ -983,14 +1051,20 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
         const int64_t a = (first_acq + it) % n_acq;
         target = targets + a * acq_stride;
         weight = weights ? weights + a * acq_stride : nullptr;
-        if (hp) {
+        if (hp) {   // gradient sums, loss and the Adam step in one launch behind the backward pass
+            FinalizeJob fin;
             if (int rc = fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, 0,
-                                                 losses ? (losses + it) : loss_sink, st, h3))
+                                                 losses ? (losses + it) : loss_sink, st, h3, fin))
                 return rc;
-        } else if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
-                                                 losses ? (losses + it) : loss_sink, st, &h3)) {
-            return rc;
+            fin.params = params;
+            fin.m = m;
+            fin.v = v;
+            if (int rc = launch_finalize(fin, first_step + it, lr, beta1, beta2, eps, st)) return rc;
+            continue;
         }
+        if (int rc = fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, 0,
+                                          losses ? (losses + it) : loss_sink, st, &h3))
+            return rc;
         if (int rc = launch_adam(params, grads, m, v, L.total, first_step + it, lr, beta1, beta2, eps, st)) return rc;
     }
     return 0;
@@ -1029,8 +1103,11 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
     if (hp_eligible(desc, L)) {
         char* xhl = base + c.xhl_off;
         if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, (hipStream_t)stream)) return rc;
-        return fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, count_total, loss,
-                                       (hipStream_t)stream, h3);
+        FinalizeJob fin;
+        if (int rc = fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, count_total, loss,
+                                             (hipStream_t)stream, h3, fin))
+            return rc;
+        return launch_finalize(fin, 0, 0.0, 0.0, 0.0, 0.0, (hipStream_t)stream);
     }
     return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
                                 (hipStream_t)stream, &h3);

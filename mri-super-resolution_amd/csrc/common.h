@@ -88,6 +88,36 @@ enum LaunchFamily {
 void count_launch(int family);
 #define INR_E_FALLBACK (-100)   // internal: the chosen kernel cannot run on this device, the caller takes its next-best path
 
+// ---- deferred gradient reduction of the fused fit (kernels.hip: finalize_kernel) -------------------------------------------
+// Every gradient tensor of a step is a fixed-order sum of slab rows its producer left behind (row-split parameter-gradient
+// GEMMs, per-tile column sums of the input-gradient epilogues, per-block sums of the head step).  Round 2 reduced each tensor
+// right behind its producer -- 9 to 14 launches of ~5 us -- and ran Adam as one more; here the producers only write, and ONE
+// launch at the end of the step sums every tensor, finishes the loss and takes the Adam step (two launches when a slab stack is
+// tall enough to want a first stage).  No float atomics anywhere: runs stay bitwise reproducible.
+constexpr int FIN_MAX_SEG = 20;
+constexpr int FIN_GROUP = 32;         // rows per first-stage group
+constexpr int FIN_TALL = 4 * FIN_GROUP;   // stacks above this many rows get a first stage
+struct FinalizeSeg {
+    const float* slab;     // [nslabs][len]
+    float* stage1;         // [ceil(nslabs / FIN_GROUP)][len] when nslabs > FIN_TALL, else unused
+    long long dst;         // offset of the tensor in the flat parameter / gradient buffers
+    long long len;
+    int nslabs;
+};
+struct FinalizeJob {
+    FinalizeSeg seg[FIN_MAX_SEG];
+    long long first[FIN_MAX_SEG + 1];   // prefix sums of len
+    int nseg;
+    const float* part_loss;             // [nparts] per-block loss terms (nullable)
+    int nparts;
+    float loss_scale;
+    float* loss_out;
+    float* grads;
+    float *params, *m, *v;              // params == nullptr: reduce only (inr_siren_loss_grad)
+    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps;
+};
+int launch_finalize(FinalizeJob& job, long long adam_step, double lr, double b1, double b2, double eps, hipStream_t st);
+
 enum KernelClass { KC_GEMM_FWD = 0, KC_GEMM_DX = 1, KC_GEMM_DW = 2, KC_OTHER = 3, KC_COUNT = 4 };
 bool prof_enabled();
 void prof_begin(int kernel_class, hipStream_t s);

@@ -812,6 +812,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const Gemm
 
 #include "gemm_h3.inc"
 #include "gemm_hp.inc"
+#include "gemm_hp_nt.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
 tune_int g_stamp_class{-1}, g_stamp_nth{0}; // hp kernels: which launch receives g_stamps (class, countdown)
@@ -1114,28 +1115,35 @@ static int hp_num_cus() {
 }
 bool hp_head_ok(int hidden) { return hidden == 128 || hidden == 256 || hidden == 512 || hidden == 1024; }
 
-int hp_weight_split(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* amax,
-                    unsigned* wnorm, hipStream_t stream) {
-    INR_REQUIRE(layers >= 1 && layers <= 8, INR_E_INVALID, "hp_weight_split: %d layers", layers);
-    WeightSplitJobs aj{};
+// per-step weight preparation (gemm_hp.inc): slots[l] = max|W_l|, slots[8 + l] = 0 (dz maxima), slots[16 + l] = wnorm_l; `part`
+// = 8 x HP_PREP_MAXB x 2 words of scratch; head_bound nullable (forward-only callers)
+size_t hp_prep_part_bytes() { return (size_t)8 * HP_PREP_MAXB * 2 * sizeof(unsigned); }
+int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* slots,
+                   unsigned* part, float* head_bound, const float* head_W, const float* head_b, int hidden, const unsigned* tmax,
+                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream) {
+    INR_REQUIRE(layers >= 1 && layers <= 8, INR_E_INVALID, "hp_weight_prep: %d layers", layers);
     HpWeightJobs jobs{};
     char* cur = planes;
-    int max_tiles = 1, max_ci = 1;
+    int max_tiles = 1, max_sb = 1;
     for (int l = 0; l < layers; ++l) {
         const long long n = (long long)out_f[l] * in_f[l];
-        aj.job[l] = WeightSplitJob{W[l], nullptr, nullptr, nullptr, nullptr, amax + l, out_f[l], in_f[l]};
-        jobs.job[l] = HpWeightJob{W[l], cur, cur + 4 * n, amax + l, wnorm + l, out_f[l], in_f[l]};
+        jobs.job[l] = HpWeightJob{W[l], cur, cur + 4 * n, slots + l, slots + 16 + l, out_f[l], in_f[l]};
         cur += 8 * n;
         const int t = ((out_f[l] + 63) / 64) * ((in_f[l] + 63) / 64);
         if (t > max_tiles) max_tiles = t;
-        if ((in_f[l] + 63) / 64 > max_ci) max_ci = (in_f[l] + 63) / 64;
+        const int sb = (in_f[l] >> 4) < HP_PREP_MAXB ? (in_f[l] >> 4) : HP_PREP_MAXB;
+        if (sb > max_sb) max_sb = sb;
     }
+    jobs.layers = layers;
+    jobs.part = part;
+    jobs.dz_slots = slots + 8;
+    jobs.head_bound = head_bound;
+    jobs.head_W = head_W; jobs.head_b = head_b; jobs.hidden = hidden;
+    jobs.tmax = tmax; jobs.wtmax = wtmax; jobs.inv_count = inv_count; jobs.omega = omega;
     ProfScope ps(KC_OTHER, stream);
-    hipLaunchKernelGGL(weight_amax_kernel, dim3(32, layers), dim3(256), 0, stream, aj);
+    hipLaunchKernelGGL(hp_weight_stats_kernel, dim3(max_sb, layers), dim3(256), 0, stream, jobs);
     INR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hp_wnorm_kernel, dim3(max_ci, layers), dim3(256), 0, stream, jobs);
-    INR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(hp_weight_split_kernel, dim3(max_tiles, layers), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL(hp_weight_split_kernel, dim3(max_tiles, layers + 1), dim3(256), 0, stream, jobs);
     INR_LAUNCH_CHECK();
     return 0;
 }
@@ -1172,6 +1180,45 @@ tune_int g_hp_zhead{1};
 tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
 bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
 
+// Which rows of a K-contiguous GEMM go to the wide persistent kernels and which to the 64 x 128 tiles of gemm_hp_nt_kernel:
+// the whole launch goes narrow when its wide tiles would keep at most three quarters of the CUs busy (four narrow tiles per
+// wide one, each a little more than a quarter of its time: gemm_hp_nt.inc), otherwise all of it stays wide.
+struct HpRowPlan {
+    int64_t wide_rows, narrow_rows;
+};
+static HpRowPlan hp_row_plan(int64_t n, int width) {
+    if (!g_hp_narrow || !g_hp_persistent) return {n, 0};
+    const long long G = hp_num_cus();
+    const long long tiles_n = (width + HP_BN - 1) / HP_BN, tiles_m = (n + HP_BM - 1) / HP_BM, tiles = tiles_m * tiles_n;
+    if (4 * tiles <= 3 * G) return {0, n};
+    // (Handing the remainder rows of a LARGE launch to the narrow tiles was measured and dropped: these kernels move their
+    //  bytes at ~3.6 TB/s whatever the tile count, so the round the remainder adds to a few CUs costs ~9 us at 69,632 rows,
+    //  less than a second launch: 1.39 against 1.34 ms per step.)
+    return {n, 0};
+}
+
+// xzy: the MFMA block order of the wide kernel that serves this K (gemm_hp_nt.inc)
+template <int EPI>
+static int hp_launch_narrow(HpParams p, int64_t row0, int64_t rows, bool xzy, hipStream_t stream) {
+    p.A += row0 * p.pitchA;
+    p.a_rows = rows;
+    p.M = (int)rows;
+    if (p.C_hl) p.C_hl += row0 * (long long)p.N * 4;
+    if (p.C2) p.C2 += row0 * (long long)p.N;
+    if (p.mul) p.mul += row0 * (long long)p.N;
+    if (p.colsum) p.colsum += 2 * (row0 / HP_BM) * (long long)p.N;   // (row0 is a multiple of the wide tile height)
+    p.tiles_m = (int)((rows + NT_BM - 1) / NT_BM);
+    p.tiles_n = (p.N + NT_BN - 1) / NT_BN;
+    p.splits = 1;
+    const long long tiles = (long long)p.tiles_m * p.tiles_n;
+    INR_REQUIRE(tiles > 0 && tiles < (1ll << 31), INR_E_INVALID, "hp narrow gemm grid out of range (%lld blocks)", tiles);
+    if (xzy) hipLaunchKernelGGL((gemm_hp_nt_kernel<EPI, true>), dim3((unsigned)tiles), dim3(NT_NTH), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_hp_nt_kernel<EPI, false>), dim3((unsigned)tiles), dim3(NT_NTH), 0, stream, p);
+    INR_LAUNCH_CHECK();
+    count_launch(LF_HP_NARROW);
+    return 0;
+}
+
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
                     int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only) {
     HpParams p{};
@@ -1181,46 +1228,62 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
     p.a_rows = n; p.b_rows = out_f;
     p.sa = sa; p.sb = sb;
     p.C_hl = act_hl; p.C2 = dact; p.bias = bias; p.omega = omega;
-    p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (out_f + HP_BN - 1) / HP_BN; p.splits = 1;
-    p.k_per_split = in_f; p.reverse_m = reverse_m; p.stagger = g_hp_stagger;
-    if (int rc = hp_check_grid(p)) return rc;
-    const long long tiles = (long long)p.tiles_m * p.tiles_n;
-    const dim3 grid((unsigned)tiles), block(HP_NTH);
+    p.k_per_split = in_f; p.reverse_m = reverse_m; p.stagger = g_hp_stagger; p.splits = 1;
+    if (z_only) INR_REQUIRE(dact && hp_z_stash_ok(in_f), INR_E_INVALID, "hp_sine_forward: z-only stash needs the deferred-epilogue kernel");
+    const HpRowPlan plan = hp_row_plan(n, out_f);
     p.stamps = hp_stamp_target(KC_GEMM_FWD);
     ProfScope ps(KC_GEMM_FWD, stream);
-    const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-    if (z_only) {   // (caller checked hp_z_stash_ok): z + b as fp32 into `dact`, nothing else
-        INR_REQUIRE(dact && hp_z_stash_ok(in_f), INR_E_INVALID, "hp_sine_forward: z-only stash needs the deferred-epilogue kernel");
-        if (in_f == 512) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 16>), pgrid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 8>), pgrid, block, 0, stream, p);
-        count_launch(LF_HP_PKD);
-    } else if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
-        if (in_f == 512) {
-            if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 16>), pgrid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 16>), pgrid, block, 0, stream, p);
+    if (plan.wide_rows > 0) {
+        p.M = (int)plan.wide_rows;
+        p.a_rows = plan.wide_rows;
+        p.tiles_m = (int)((plan.wide_rows + HP_BM - 1) / HP_BM); p.tiles_n = (out_f + HP_BN - 1) / HP_BN;
+        if (int rc = hp_check_grid(p)) return rc;
+        const long long tiles = (long long)p.tiles_m * p.tiles_n;
+        const dim3 grid((unsigned)tiles), block(HP_NTH);
+        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+        if (z_only) {   // z + b as fp32 into `dact`, nothing else
+            if (in_f == 512) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 16>), pgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 8>), pgrid, block, 0, stream, p);
+            count_launch(LF_HP_PKD);
+        } else if (g_hp_persistent == 2 && (in_f == 512 || in_f == 256)) {   // epilogue of tile T under the K-loop of tile T+1
+            if (in_f == 512) {
+                if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 16>), pgrid, block, 0, stream, p);
+                else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 16>), pgrid, block, 0, stream, p);
+            } else {
+                if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 8>), pgrid, block, 0, stream, p);
+                else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 8>), pgrid, block, 0, stream, p);
+            }
+            count_launch(LF_HP_PKD);
+        } else if (g_hp_persistent && in_f >= 3 * HP_BK) {
+            if (dact) hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE_STASH>), pgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE>), pgrid, block, 0, stream, p);
+            count_launch(LF_HP_PKC);
+        } else if (dact) {
+            hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
+            count_launch(LF_HP_TILE);
         } else {
-            if (dact) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE_STASH, 8>), pgrid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_SINE, 8>), pgrid, block, 0, stream, p);
+            hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
+            count_launch(LF_HP_TILE);
         }
-        count_launch(LF_HP_PKD);
-    } else if (g_hp_persistent && in_f >= 3 * HP_BK) {
-        if (dact) hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE_STASH>), pgrid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_SINE>), pgrid, block, 0, stream, p);
-        count_launch(LF_HP_PKC);
-    } else if (dact) {
-        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE_STASH>), grid, block, 0, stream, p);
-        count_launch(LF_HP_TILE);
-    } else {
-        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_SINE>), grid, block, 0, stream, p);
-        count_launch(LF_HP_TILE);
+        INR_LAUNCH_CHECK();
     }
-    INR_LAUNCH_CHECK();
+    if (plan.narrow_rows > 0) {
+        p.stamps = nullptr;
+        const bool xzy = g_hp_persistent == 2 && (in_f == 512 || in_f == 256);   // the rule of the wide dispatch above
+        p.fold_bias = (g_hp_persistent && in_f >= 3 * HP_BK) ? 1 : 0;
+        if (z_only) return hp_launch_narrow<HPE_Z>(p, plan.wide_rows, plan.narrow_rows, xzy, stream);
+        if (dact) return hp_launch_narrow<HPE_SINE_STASH>(p, plan.wide_rows, plan.narrow_rows, xzy, stream);
+        return hp_launch_narrow<HPE_SINE>(p, plan.wide_rows, plan.narrow_rows, xzy, stream);
+    }
     return 0;
 }
 
-// dz_prev (HL32 * 2^ko, written over the bytes of `mul`) = (dz W) * mul; colsum slab [2 ceil(n/128)][in_f]; max|dz_prev|
+// rows of column sums an input-grad launch may write (two per 64-row tile is the finest any of the kernels goes)
+int hp_input_grad_max_rows(int64_t n) { return 2 * (int)((n + 63) / 64); }
+
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
-                  float* colsum_slab, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so, hipStream_t stream) {
+                  float* colsum_slab, int* colsum_rows, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so,
+                  hipStream_t stream) {
     HpParams p{};
     p.A = dz_hl; p.B = WT_hl;
     p.M = (int)n; p.N = in_f; p.K = out_f;
@@ -1228,25 +1291,36 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
     p.a_rows = n; p.b_rows = in_f;
     p.sa = sa; p.sb = sb; p.so = so;
     p.C_hl = dzprev_hl; p.mul = mul; p.colsum = colsum_slab; p.amax_out = amax_out;
-    p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = (in_f + HP_BN - 1) / HP_BN; p.splits = 1;
+    p.splits = 1;
     p.k_per_split = out_f; p.stagger = g_hp_stagger;
-    if (int rc = hp_check_grid(p)) return rc;
-    const long long tiles = (long long)p.tiles_m * p.tiles_n;
-    const dim3 grid((unsigned)tiles), block(HP_NTH);
+    const HpRowPlan plan = hp_row_plan(n, in_f);
+    *colsum_rows = 2 * (int)((plan.wide_rows + HP_BM - 1) / HP_BM) + 2 * (int)((plan.narrow_rows + NT_BM - 1) / NT_BM);
     p.stamps = hp_stamp_target(KC_GEMM_DX);
     ProfScope ps(KC_GEMM_DX, stream);
-    const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-    if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
-        hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_MUL, 16>), pgrid, block, 0, stream, p);
-        count_launch(LF_HP_PKD);
-    } else if (g_hp_persistent && out_f >= 3 * HP_BK) {
-        hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_MUL>), pgrid, block, 0, stream, p);
-        count_launch(LF_HP_PKC);
-    } else {
-        hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
-        count_launch(LF_HP_TILE);
+    if (plan.wide_rows > 0) {
+        p.M = (int)plan.wide_rows;
+        p.a_rows = plan.wide_rows;
+        p.tiles_m = (int)((plan.wide_rows + HP_BM - 1) / HP_BM); p.tiles_n = (in_f + HP_BN - 1) / HP_BN;
+        if (int rc = hp_check_grid(p)) return rc;
+        const long long tiles = (long long)p.tiles_m * p.tiles_n;
+        const dim3 grid((unsigned)tiles), block(HP_NTH);
+        const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
+        if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
+            hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_MUL, 16>), pgrid, block, 0, stream, p);
+            count_launch(LF_HP_PKD);
+        } else if (g_hp_persistent && out_f >= 3 * HP_BK) {
+            hipLaunchKernelGGL((gemm_hp_pkc_kernel<HPE_MUL>), pgrid, block, 0, stream, p);
+            count_launch(LF_HP_PKC);
+        } else {
+            hipLaunchKernelGGL((gemm_hp_kernel<HP_KC, HPE_MUL>), grid, block, 0, stream, p);
+            count_launch(LF_HP_TILE);
+        }
+        INR_LAUNCH_CHECK();
     }
-    INR_LAUNCH_CHECK();
+    if (plan.narrow_rows > 0) {
+        p.stamps = nullptr;
+        return hp_launch_narrow<HPE_MUL>(p, plan.wide_rows, plan.narrow_rows, g_hp_persistent == 2 && out_f == 512, stream);
+    }
     return 0;
 }
 
@@ -1254,7 +1328,7 @@ int hp_param_grad_splits(int64_t n, int in_f, int out_f) {
     const long long tiles = (long long)((out_f + HP_BM - 1) / HP_BM) * ((in_f + HP_BN - 1) / HP_BN);
     const long long ksteps = (n + HP_BK - 1) / HP_BK;
     long long want = (256 + tiles - 1) / tiles;          // one 512-thread block per CU
-    const long long max_by_work = (ksteps + 15) / 16;    // at least 16 K-tiles per split
+    const long long max_by_work = (ksteps + 7) / 8;      // at least 8 K-tiles per split
     long long s = want < max_by_work ? want : max_by_work;
     const long long min_by_offset = (n * (long long)(in_f > out_f ? in_f : out_f) * 4 + (1ll << 30) - 1) >> 30;   // 32-bit offsets
     if (s < min_by_offset) s = min_by_offset;
@@ -1294,14 +1368,6 @@ int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char*
     return 0;
 }
 
-int hp_head_bound(float* out, const float* W, const float* bias, int hidden, const unsigned* tmax, const unsigned* wtmax,
-                  float inv_count, float omega, hipStream_t stream) {
-    ProfScope ps(KC_OTHER, stream);
-    hipLaunchKernelGGL(hp_head_bound_kernel, dim3(1), dim3(256), 0, stream, out, W, bias, hidden, tmax, wtmax, inv_count, omega);
-    INR_LAUNCH_CHECK();
-    return 0;
-}
-
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
                     float clamp_min, hipStream_t stream) {
     long long blocks = (n + 3) / 4;
@@ -1319,12 +1385,24 @@ int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bia
     return 0;
 }
 
-// slab_b / slab_w: [blocks][hidden], part_loss / part_g: [blocks], blocks = ceil(n / 256)
+// rows per block of the head step: at most 256 (what the large fits ran with), fewer when that would leave CUs idle
+// (round 2: 16 blocks at 4,096 rows, 49 us for 8 MB)
+int hp_head_rows_per_block(int64_t n) {
+    long long r = (n + 1023) / 1024;
+    r = (r + 3) / 4 * 4;
+    return (int)(r < 16 ? 16 : (r > 256 ? 256 : r));
+}
+int64_t hp_head_blocks(int64_t n) {
+    const int rpb = hp_head_rows_per_block(n);
+    return (n + rpb - 1) / rpb;
+}
+
+// slab_b / slab_w: [blocks][hidden], part_loss / part_g: [blocks], blocks = hp_head_blocks(n)
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
                  int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z, float omega) {
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
-    const int rpb = 256;
+    const int rpb = hp_head_rows_per_block(n);
     const dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
     ProfScope ps(KC_OTHER, stream);
 #define HP_HEAD_STEP(CPL)                                                                                                   \

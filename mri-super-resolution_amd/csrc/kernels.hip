@@ -355,6 +355,77 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ o
     out[(int64_t)blockIdx.y * len + i] = (a0 + a1) + (a2 + a3);
 }
 
+// ---- deferred reduction + loss + Adam of a fused step (common.h: FinalizeJob) ---------------------------------------------
+// first stage for tall slab stacks: grid (ceil(max len / 256), max groups, segments)
+__global__ void __launch_bounds__(256) finalize_stage1_kernel(const FinalizeJob job) {
+    const FinalizeSeg sg = job.seg[blockIdx.z];
+    if (sg.nslabs <= FIN_TALL) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s0 = blockIdx.y * FIN_GROUP;
+    if (i >= sg.len || s0 >= sg.nslabs) return;
+    const int s1 = min(sg.nslabs, s0 + FIN_GROUP);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+        a0 += sg.slab[(int64_t)s * sg.len + i];
+        a1 += sg.slab[(int64_t)(s + 1) * sg.len + i];
+        a2 += sg.slab[(int64_t)(s + 2) * sg.len + i];
+        a3 += sg.slab[(int64_t)(s + 3) * sg.len + i];
+    }
+    for (; s < s1; ++s) a0 += sg.slab[(int64_t)s * sg.len + i];
+    sg.stage1[(int64_t)blockIdx.y * sg.len + i] = (a0 + a1) + (a2 + a3);
+}
+
+// one thread per gradient element: fixed-order sum of its slab column, gradient out, Adam step (torch's single-tensor
+// formulation, as adam_kernel); the block behind the last element block finishes the loss
+__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeJob job) {
+    const int64_t total = job.first[job.nseg];
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 256 >= total) {   // the loss block
+        if (!job.part_loss) return;
+        __shared__ float red[256];
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < job.nparts; i += 256) acc += job.part_loss[i];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) job.loss_out[0] = red[0] * job.loss_scale;
+        return;
+    }
+    if (e >= total) return;
+    int k = 0;
+    while (e >= job.first[k + 1]) ++k;
+    const FinalizeSeg sg = job.seg[k];
+    const int64_t i = e - job.first[k];
+    const bool tall = sg.nslabs > FIN_TALL;
+    const float* src = tall ? sg.stage1 : sg.slab;
+    const int ns = tall ? (sg.nslabs + FIN_GROUP - 1) / FIN_GROUP : sg.nslabs;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < ns; s += 4) {
+        a0 += src[(int64_t)s * sg.len + i];
+        a1 += src[(int64_t)(s + 1) * sg.len + i];
+        a2 += src[(int64_t)(s + 2) * sg.len + i];
+        a3 += src[(int64_t)(s + 3) * sg.len + i];
+    }
+    for (; s < ns; ++s) a0 += src[(int64_t)s * sg.len + i];
+    const float gi = (a0 + a1) + (a2 + a3);
+    const int64_t at = sg.dst + i;
+    job.grads[at] = gi;
+    if (job.params) {
+        const float m0 = job.m[at], v0 = job.v[at];
+        const float mi = fmaf(gi - m0, job.one_minus_b1, m0);
+        const float vi = fmaf(job.one_minus_b2 * gi, gi, v0 * job.b2);
+        const float denom = __fsqrt_rn(vi) / job.bc2_sqrt + job.eps;
+        job.m[at] = mi;
+        job.v[at] = vi;
+        job.params[at] = job.params[at] - job.step_size * (mi / denom);
+    }
+}
+
 // ---- a-7: Adam (torch single-tensor formulation) ---------------------------------------------------
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t count,
@@ -576,6 +647,44 @@ int launch_head_step_fused(float* dz, float* slab_b, float* slab_w, float* part_
 int launch_finish_sum(float* out, const float* partial, int nparts, float scale, hipStream_t st) {
     ProfScope ps(KC_OTHER, st);
     hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, st, out, partial, nparts, scale);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// sums every segment of `job`, finishes the loss and -- when job.params is set -- takes Adam step number `adam_step`
+int launch_finalize(FinalizeJob& job, long long adam_step, double lr, double b1, double b2, double eps, hipStream_t st) {
+    INR_REQUIRE(job.nseg >= 1 && job.nseg <= FIN_MAX_SEG, INR_E_INVALID, "finalize: %d segments", job.nseg);
+    job.first[0] = 0;
+    long long max_len = 0;
+    int max_groups = 0;
+    for (int k = 0; k < job.nseg; ++k) {
+        job.first[k + 1] = job.first[k] + job.seg[k].len;
+        if (job.seg[k].nslabs > FIN_TALL) {
+            INR_REQUIRE(job.seg[k].stage1 != nullptr, INR_E_INVALID, "finalize: tall segment %d without a first-stage buffer", k);
+            if (job.seg[k].len > max_len) max_len = job.seg[k].len;
+            const int g = (job.seg[k].nslabs + FIN_GROUP - 1) / FIN_GROUP;
+            if (g > max_groups) max_groups = g;
+        }
+    }
+    if (job.params) {
+        const double bc1 = 1.0 - pow(b1, (double)adam_step), bc2 = 1.0 - pow(b2, (double)adam_step);
+        job.one_minus_b1 = (float)(1.0 - b1);
+        job.b2 = (float)b2;
+        job.one_minus_b2 = (float)(1.0 - b2);
+        job.step_size = (float)(lr / bc1);
+        job.bc2_sqrt = (float)sqrt(bc2);
+        job.eps = (float)eps;
+    }
+    ProfScope ps(KC_OTHER, st);
+    if (max_groups > 0) {
+        INR_REQUIRE(max_groups <= 65535, INR_E_INVALID, "finalize: slab stack too tall (%d groups)", max_groups);
+        hipLaunchKernelGGL(finalize_stage1_kernel, dim3((unsigned)((max_len + 255) / 256), (unsigned)max_groups, (unsigned)job.nseg),
+                           dim3(256), 0, st, job);
+        INR_LAUNCH_CHECK();
+    }
+    const long long blocks = (job.first[job.nseg] + 255) / 256 + 1;   // + the loss block
+    INR_REQUIRE(blocks < (1ll << 31), INR_E_INVALID, "finalize: too many elements");
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, job);
     INR_LAUNCH_CHECK();
     return 0;
 }

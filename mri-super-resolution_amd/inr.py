@@ -88,13 +88,13 @@ class ImageFitting_set(torch.utils.data.Dataset):
         if pil_like:  # nn_mri flavour: ToTensor then Normalize(0.5, 0.5): pixel -> 2*pixel - 1 (nn_mri.py:174-180)
             # torchvision's ToTensor divides 8-bit images (PIL mode 'L' -> uint8) by 255 and leaves every other mode as it
             # is ('F' float32 -- what master.py:122 passes -- and 'I' int32 are only cast)
-            arrays = [np.array(im) for im in img_dataset]
-            arrays = [a.astype(np.float32) / 255.0 if a.dtype == np.uint8 else a for a in arrays]
-            side = arrays[0].shape[0]
-            if any(a.shape != (side, side) for a in arrays):
+            raw = [np.array(im) for im in img_dataset]
+            side = raw[0].shape[0]
+            if any(a.shape != (side, side) for a in raw):
                 raise ValueError("nn_mri-style ImageFitting_set needs square images of equal size")
-            self.orig = np.stack([a.astype(np.float64) for a in arrays])
+            self.orig = np.stack([a.astype(np.float64) for a in raw])        # nn_mri.py:192: np.array(img) as it is
             self.mean = sum(self.orig) / len(self.orig)
+            arrays = [a.astype(np.float32) / 255.0 if a.dtype == np.uint8 else a for a in raw]
             self.shape = tuple(first.size)
             flat = [(2.0 * torch.from_numpy(a).float() - 1.0).reshape(-1, 1) for a in arrays]
             grid_shape = (side, side)
