@@ -13,24 +13,33 @@ eps = 1e-7      # master.py:42
 mag = 1000      # master.py:43
 
 
+_PATIENT_FILES = {"dwi": ("_alldata.mat", "data"), "b0": ("_mean_b0.mat", "data_mean_b0"), "erd": ("_ERD.mat", "ADC_alldata_mm_ERD")}
+
+
+def _patient_array(data_dir, pt_no, kind, required=True):
+    suffix, key = _PATIENT_FILES[kind]
+    path = os.path.join(data_dir, f"pat{pt_no}{suffix}")
+    if not required and not os.path.exists(path):
+        return None
+    return matio.loadmat(path)[key]
+
+
 class case:
-    """nn_mri.py:28-56: one patient of the 2-D study.  ``data_dir`` (default ``../anon_data`` as in the reference) holds
-    ``pat<NN>_alldata.mat`` (``data`` [X, Y, Z, acquisitions]), ``pat<NN>_mean_b0.mat`` and ``pat<NN>_ERD.mat``."""
+    """One patient of the 2-D study -- the record ``master.py`` iterates over (constructor arguments and attribute names are
+    the reference's, nn_mri.py:28-56, because the driver reads them: ``pt_id, b, cancer_loc, contralateral_loc, noise,
+    cancer_slice, acquisitions`` plus the loaded ``dwi`` [X, Y, Z, acquisitions], ``b0``, ``accept`` (all ones) and ``erd``).
+    ``data_dir`` defaults to the reference's ``../anon_data``; the ERD file is optional here (it is stripped from the
+    published data), the other two are not."""
 
     def __init__(self, pt_id, b, cancer_loc, contralateral_loc, noise, cancer_slice, acquisitions, data_dir="../anon_data"):
-        self.pt_id = pt_id
-        self.cancer_loc = cancer_loc
-        self.contralateral_loc = contralateral_loc
-        self.noise = noise
-        self.cancer_slice = cancer_slice
-        self.acquisitions = acquisitions
-        self.b = b
-        pt_no = self.pt_id.split('-')[-1]
-        self.dwi = matio.loadmat(os.path.join(data_dir, 'pat' + pt_no + '_alldata.mat'))['data']
-        self.b0 = matio.loadmat(os.path.join(data_dir, 'pat' + pt_no + '_mean_b0.mat'))['data_mean_b0']
+        self.pt_id, self.b = pt_id, b
+        self.cancer_loc, self.contralateral_loc, self.noise = cancer_loc, contralateral_loc, noise
+        self.cancer_slice, self.acquisitions = cancer_slice, acquisitions
+        pt_no = pt_id.split("-")[-1]
+        self.dwi = _patient_array(data_dir, pt_no, "dwi")
+        self.b0 = _patient_array(data_dir, pt_no, "b0")
+        self.erd = _patient_array(data_dir, pt_no, "erd", required=False)
         self.accept = np.ones(self.dwi.shape, dtype=int)
-        erd_path = os.path.join(data_dir, 'pat' + pt_no + '_ERD.mat')
-        self.erd = matio.loadmat(erd_path)['ADC_alldata_mm_ERD'] if os.path.exists(erd_path) else None
 
 
 # master.py:1 imports a module-level list ``cases`` that nn_mri.py never defines (the patient table was not published);
@@ -38,22 +47,22 @@ class case:
 cases = []
 
 
+def _square(image, centre, focus, scale):
+    """The 2*scale-wide square around a landmark given in full-image pixels, on an image whose origin is ``focus`` and
+    whose pixels are 1/scale of the original."""
+    r, c = ((int(v) - focus) * scale for v in centre)
+    return np.asarray(image)[r - scale:r + scale, c - scale:c + scale]
+
+
 def calculate_contrast(case, scale, image, focus):
-    """nn_mri.py:59-85: contrast C, CNR and CNR2 between the 2*scale-wide squares around the cancer, contralateral and
-    noise locations (given in full-image pixels; ``focus`` = ROI origin).  Same arithmetic, same order."""
-    cc_x, cc_y = tuple((i - focus) * scale for i in case.cancer_loc)
-    cb_x, cb_y = tuple((i - focus) * scale for i in case.contralateral_loc)
-    cn_x, cn_y = tuple((i - focus) * scale for i in case.noise)
-    cancer_area = image[cc_x - scale: cc_x + scale, cc_y - scale: cc_y + scale]
-    contralateral_area = image[cb_x - scale: cb_x + scale, cb_y - scale: cb_y + scale]
-    noise_area = image[cn_x - scale: cn_x + scale, cn_y - scale: cn_y + scale]
-    varc = np.std(cancer_area) ** 2
-    varb = np.std(contralateral_area) ** 2
-    varn = np.std(noise_area)           # (the reference divides by the noise STANDARD DEVIATION and calls it a variance)
-    C = cancer_area.mean() / (contralateral_area.mean() + 1e-7)
-    CNR = abs(cancer_area.mean() - contralateral_area.mean()) / np.sqrt(varc + varb)
-    CNR2 = abs(cancer_area.mean() - contralateral_area.mean()) / varn
-    return C, CNR, CNR2
+    """Lesion conspicuity of one image (nn_mri.py:59-85): ratio of the mean signal in the square around the lesion to the one
+    around its contralateral mirror point, their difference over the pooled standard deviation of the two squares, and the same
+    difference over the standard deviation of a background square (the reference names that last divisor a variance; it is a
+    standard deviation, kept).  Returns ``(C, CNR, CNR2)``; pinned by tests/golden/contrast.npz."""
+    lesion, mirror, background = (_square(image, p, focus, scale) for p in (case.cancer_loc, case.contralateral_loc, case.noise))
+    gap = abs(lesion.mean() - mirror.mean())
+    pooled = np.sqrt(np.std(lesion) ** 2 + np.std(mirror) ** 2)
+    return lesion.mean() / (mirror.mean() + 1e-7), gap / pooled, gap / np.std(background)
 
 
 def minmax_normalize(img, ref):

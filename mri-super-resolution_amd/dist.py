@@ -54,7 +54,63 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
     return groups
 
 
-def plan_fits(costs: Sequence[float], world_size: int, shard_overhead: float = 0.03) -> Dict[str, object]:
+# Fit-step time of Siren(256,512,3,1) on one MI355X, milliseconds per step by row count: MEASURED in round 3
+# (tools/step_time_table.py -> profiles/r03_step_time_table.json).  `fused` = inr_siren_fit (a whole volume on one rank),
+# `sharded` = inr_siren_loss_grad + inr_adam_step per step (what a gang member runs between two all-reduces).  A step is not
+# linear in the rows: ~0.15 ms of it is fixed (kernel ramp-up / drain of ~16 launches), which is what makes row-sharding cost
+# GPU time -- three 46,421-row shards take 3 x 0.97 = 2.9 ms where the whole 139,264-row volume takes 2.42.
+STEP_TIME_TABLE_MS = (
+    # rows, fused, sharded
+    (4096, 0.2166, 0.2802), (16384, 0.4577, 0.5214), (32768, 0.6791, 0.7537), (46421, 0.8898, 0.9700), (65536, 1.1925, 1.2782),
+    (69632, 1.3243, 1.4166), (98304, 1.7211, 1.8129), (114688, 1.9860, 2.0741), (139264, 2.4223, 2.5241), (262144, 4.4010, 4.5508),
+    (524288, 8.6920, 8.9444),
+)
+GRADIENT_BYTES = 3_682_320          # flat fp32 gradient of Siren(256,512,3,1) + the loss slot: one all-reduce per step
+
+
+class StepTimeModel:
+    """Seconds a fit takes on `k` ranks: steps x (t(rows / k) + all-reduce(k)).  t(.) interpolates the measured table (linear
+    between the points, the outer segments extended); the all-reduce term is MODELLED -- no multi-GPU node was available to
+    measure RCCL on: a ring over k GPUs moves 2 (k - 1) / k x the gradient over one xGMI link per GPU (153 GB/s peak per
+    direction, `link_gbps` of it assumed reachable) plus `latency_us` per collective."""
+
+    def __init__(self, table=STEP_TIME_TABLE_MS, link_gbps: float = 75.0, latency_us: float = 30.0, overhead_s: float = 0.12):
+        self.rows = [float(r[0]) for r in table]
+        self.fused = [float(r[1]) for r in table]
+        self.sharded = [float(r[2]) for r in table]
+        self.link_gbps, self.latency_us = float(link_gbps), float(latency_us)
+        self.overhead_s = float(overhead_s)     # per fit: Fourier features, re-sampling on both grids, PSNR / SSIM (measured ~0.1 s)
+
+    @classmethod
+    def from_json(cls, path: str, **kw):
+        import json
+        with open(path) as fh:
+            t = json.load(fh)["table"]
+        return cls(tuple((r["rows"], r["fused_ms_per_step"], r["sharded_ms_per_step"]) for r in t), **kw)
+
+    def _interp(self, ys, n: float) -> float:
+        xs = self.rows
+        i = 1
+        while i < len(xs) - 1 and n > xs[i]:
+            i += 1
+        x0, x1, y0, y1 = xs[i - 1], xs[i], ys[i - 1], ys[i]
+        return max(y0 + (y1 - y0) * (n - x0) / (x1 - x0), 0.02)
+
+    def allreduce_ms(self, k: int, nbytes: int = GRADIENT_BYTES) -> float:
+        if k <= 1:
+            return 0.0
+        return self.latency_us * 1e-3 + 2.0 * (k - 1) / k * nbytes / (self.link_gbps * 1e9) * 1e3
+
+    def step_ms(self, rows: float, k: int = 1) -> float:
+        if k <= 1:
+            return self._interp(self.fused, rows)
+        return self._interp(self.sharded, -(-rows // k)) + self.allreduce_ms(k)
+
+    def fit_seconds(self, rows: float, steps: int, k: int = 1) -> float:
+        return steps * self.step_ms(rows, k) * 1e-3 + self.overhead_s
+
+
+def plan_fits(costs: Sequence[float], world_size: int, shard_overhead: float = 0.03, shard_time=None) -> Dict[str, object]:
     """Schedule with row-sharded fits (SURVEY.md 8 e): whole-volume packing alone tops out at 6.04x on the reference's
     11 patients and 8 GPUs, because three ranks get two volumes.  Here the jobs that do not fill a whole round are run
     FIRST as a gang phase -- every such job split over its own group of ranks (``ShardedSirenFitter``: one gradient
@@ -62,38 +118,60 @@ def plan_fits(costs: Sequence[float], world_size: int, shard_overhead: float = 0
     partner -- and the remaining jobs are packed whole, LPT, on top of the group finish times.
 
     Candidates: plain LPT; a gang phase with the r largest jobs, or with the r smallest, for every r up to min(n, world).
-    The cheapest by the cost model wins (sharded time = cost / k * (1 + shard_overhead)).  Deterministic.
-    Returns {"gangs": [(job, [ranks])...], "whole": [[job...] per rank], "makespan": modelled time}."""
+    The cheapest by the cost model wins.  Cost model: ``shard_time(job, k)`` = time of job on k ranks (k = 1: the whole job
+    on one rank) when given -- ``run_volumes`` passes the MEASURED step-time table (``StepTimeModel``) -- else the abstract
+    ``costs[job] / k * (1 + shard_overhead)``.  Deterministic.
+    Returns {"gangs": [(job, [ranks])...], "whole": [[job...] per rank], "makespan": modelled time, "loads": per-rank time}."""
     if world_size < 1:
         raise ValueError("world_size must be >= 1")
     n = len(costs)
     c = [float(x) for x in costs]
+    if shard_time is None:
+        def shard_time(j, k):
+            return c[j] / k * (1.0 + (shard_overhead if k > 1 else 0.0))
+    whole_t = [float(shard_time(j, 1)) for j in range(n)]
 
     def finish(gang_jobs):
         gangs, start = [], [0.0] * world_size
         if gang_jobs:
             groups = _split_ranks(world_size, [c[j] for j in gang_jobs])
             for j, ranks in zip(gang_jobs, groups):
-                t = c[j] / len(ranks) * (1.0 + (shard_overhead if len(ranks) > 1 else 0.0))
+                t = float(shard_time(j, len(ranks)))
                 for r in ranks:
                     start[r] = t
                 gangs.append((j, ranks))
-        rest = sorted((i for i in range(n) if i not in set(gang_jobs)), key=lambda i: (-c[i], i))
+        rest = sorted((i for i in range(n) if i not in set(gang_jobs)), key=lambda i: (-whole_t[i], i))
         loads, whole = list(start), [[] for _ in range(world_size)]
         for i in rest:
             r = min(range(world_size), key=lambda k: (loads[k], k))
             whole[r].append(i)
-            loads[r] += c[i]
-        return {"gangs": gangs, "whole": whole, "makespan": max(loads, default=0.0)}
+            loads[r] += whole_t[i]
+        return {"gangs": gangs, "whole": whole, "makespan": max(loads, default=0.0), "loads": loads}
 
-    by_cost = sorted(range(n), key=lambda i: (-c[i], i))
+    by_cost = sorted(range(n), key=lambda i: (-whole_t[i], i))
     candidates = [finish([])]
     if world_size > 1:
         for r in range(1, min(n, world_size) + 1):          # gang phase with the r largest / the r smallest jobs
             candidates.append(finish(by_cost[:r]))
             if r < n:
-                candidates.append(finish(sorted(by_cost[-r:], key=lambda i: (-c[i], i))))
+                candidates.append(finish(sorted(by_cost[-r:], key=lambda i: (-whole_t[i], i))))
     return min(candidates, key=lambda p: p["makespan"])     # ties: the earlier (simpler) candidate
+
+
+_GROUPS: Dict[tuple, object] = {}
+
+
+def rank_group(ranks: Sequence[int]):
+    """The process group of `ranks` (None for a single rank), created once per process and reused: ``new_group`` is collective
+    over the default group and never freed by torch, so drivers that are called repeatedly (one ``fit_hybrid`` per slice, one
+    ``run_volumes`` per batch) must not make new ones each time.  Every rank must ask for the same groups in the same order."""
+    ranks = tuple(int(r) for r in ranks)
+    if len(ranks) <= 1:
+        return None
+    key = (dist.get_world_size(), ranks)
+    if key not in _GROUPS:
+        _GROUPS[key] = dist.new_group(list(ranks))
+    return _GROUPS[key]
 
 
 def makespan(costs: Sequence[float], plan: Sequence[Sequence[int]]) -> float:

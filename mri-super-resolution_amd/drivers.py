@@ -287,8 +287,8 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
     spread = distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
     rank = torch.distributed.get_rank() if spread else 0
     te_ranks = hybrid_te_groups(torch.distributed.get_world_size()) if spread else [[0]] * 4
-    # (new_group is collective over the default group: every rank creates every group, in the same order)
-    te_groups = [torch.distributed.new_group(r) if spread and len(r) > 1 else None for r in te_ranks]
+    # (group creation is collective over the default group: every rank asks for every group, in the same order; cached)
+    te_groups = [inr_dist.rank_group(r) if spread else None for r in te_ranks]
     if spread:
         recon_hybrid.zero_()
     owned = []
@@ -329,20 +329,43 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
             "t_recon": t_recon, "t_hybrid_fit": t_hybrid, "final_losses": losses, "slice_index": k, "owned_te": owned}
 
 
-def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True,
+def plan_volumes(volumes: Sequence[np.ndarray], steps: int, world: int, allow_sharding: bool = True, **fit_kwargs):
+    """The schedule ``run_volumes`` follows (same on every rank, no communication).  For the reference's network
+    (Siren(256, 512, 3, 1): the defaults of ``fit_volume``) the planner prices a job with the MEASURED step-time table of
+    ``dist.StepTimeModel`` -- a step is not linear in the rows, which is what decides whether row-sharding pays -- otherwise
+    with rows x steps."""
+    rows = [float(np.prod([-(-s // 2) if a < 2 else s for a, s in enumerate(v.shape)])) for v in volumes]
+    costs = [r * steps for r in rows]
+    default_net = (fit_kwargs.get("hidden_features", 512) == 512 and fit_kwargs.get("hidden_layers", 3) == 3 and
+                   fit_kwargs.get("mapping_size", 128) == 128 and fit_kwargs.get("downsample", True))
+    shard_time = None
+    if default_net:
+        model = inr_dist.StepTimeModel()
+        shard_time = lambda j, k: model.fit_seconds(rows[j], steps, k)     # noqa: E731
+    if allow_sharding and world > 1:
+        plan = inr_dist.plan_fits(costs, world, shard_time=shard_time)
+    else:
+        whole = inr_dist.partition_fits([shard_time(j, 1) for j in range(len(rows))] if shard_time else costs, world)
+        t = (lambda j: shard_time(j, 1)) if shard_time else (lambda j: costs[j])
+        loads = [sum(t(j) for j in jobs) for jobs in whole]
+        plan = {"gangs": [], "whole": whole, "makespan": max(loads, default=0.0), "loads": loads}
+    plan["one_rank"] = sum(shard_time(j, 1) for j in range(len(rows))) if shard_time else sum(costs)
+    plan["unit"] = "seconds (measured step-time table, modelled all-reduce)" if shard_time else "rows x steps"
+    return plan
+
+
+def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True, stats: Optional[dict] = None,
                 **fit_kwargs) -> List[Dict[str, float]]:
     """Fits every volume once over the ranks of the current process group and returns the gathered per-fit metric
-    records on every rank (one RCCL all_gather).  Schedule: ``dist.plan_fits`` -- the volumes that do not fill a whole
-    round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
-    ``allow_sharding=False`` is plain LPT packing (no collective on the data path at all)."""
+    records on every rank (one RCCL all_gather).  Schedule: ``plan_volumes`` / ``dist.plan_fits`` -- the volumes that do not
+    fill a whole round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
+    ``allow_sharding=False`` is plain LPT packing (no collective on the data path at all).  ``stats`` (a dict) receives the
+    plan and this rank's busy seconds."""
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
-    costs = [float(np.prod([s // 2 if a < 2 else s for a, s in enumerate(v.shape)])) * steps for v in volumes]
-    if allow_sharding and world > 1:
-        plan = inr_dist.plan_fits(costs, world)
-    else:
-        plan = {"gangs": [], "whole": inr_dist.partition_fits(costs, world)}
+    plan = plan_volumes(volumes, steps, world, allow_sharding, **fit_kwargs)
     local = []
+    t_start = time.perf_counter()
 
     def record(job, res):
         local.append({"job": job, "n_coords": res["n_coords"], "steps": steps, "t_fit": res["t_fit"],
@@ -350,7 +373,7 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
                       "ssim_mean": res.get("ssim_mean", float("nan")), "final_loss": res["final_loss"]})
 
     # gang phase: every rank creates every group (new_group is collective over the default group), then works in its own
-    groups = [(job, ranks, torch.distributed.new_group(ranks) if len(ranks) > 1 else None) for job, ranks in plan["gangs"]]
+    groups = [(job, ranks, inr_dist.rank_group(ranks)) for job, ranks in plan["gangs"]]
     for job, ranks, grp in groups:
         if rank in ranks:
             res = fit_volume(volumes[job], steps=steps, return_recon=False, group=grp, **fit_kwargs)
@@ -358,6 +381,10 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
                 record(job, res)
     for job in plan["whole"][rank]:
         record(job, fit_volume(volumes[job], steps=steps, return_recon=False, **fit_kwargs))
+    if stats is not None:
+        torch.cuda.synchronize()
+        stats["busy_s"] = time.perf_counter() - t_start
+        stats["plan"] = plan
     max_jobs = max((len(p) for p in plan["whole"]), default=0) + 1
     records = inr_dist.gather_job_records(local, RECORD_KEYS, max_jobs)
     return sorted(records, key=lambda r: r["job"])

@@ -442,6 +442,33 @@ class ShardedSirenFitter(SirenFitter):
             losses[it:it + 1].copy_(self._loss)   # device-side, no host sync
         return losses[:n_steps]
 
+    def step_cycle(self, model_input, targets, n_steps, weights=None, first_acq=0):
+        """The cycling-acquisition loop (master.py:137-148) on a row-sharded fit: ``targets`` / ``weights`` are this rank's
+        [n_acq, local rows]; every step is local forward/backward on acquisition ``(first_acq + it) % n_acq``, the one
+        all-reduce, the identical Adam step.  (The base class would run the fused kernel on the local shard alone -- no
+        all-reduce, local row count in the mean -- and the replicas would drift apart.)"""
+        self._check_views()
+        x = model_input.detach().reshape(-1, model_input.shape[-1]).contiguous()
+        t = targets.detach().reshape(targets.shape[0], -1).contiguous()
+        w = None if weights is None else weights.detach().reshape(weights.shape[0], -1).contiguous()
+        if w is not None and tuple(w.shape) != tuple(t.shape):
+            raise ValueError("weights must have the shape of targets")
+        n_acq = t.shape[0]
+        if not 0 <= int(first_acq) < n_acq:
+            raise ValueError("first_acq out of range")
+        losses = torch.empty(max(int(n_steps), 1), dtype=torch.float32, device=x.device)
+        count_total = self.global_rows * self.desc.out_features
+        for it in range(int(n_steps)):
+            a = (int(first_acq) + it) % n_acq
+            self._workspace = ops.siren_loss_grad(self.desc, self.flat, self.grads, x, t[a], None if w is None else w[a],
+                                                  count_total, self._loss, self._workspace)
+            self._all_reduce(self._gbuf)
+            self.step_count += 1
+            ops.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
+                          self.eps)
+            losses[it:it + 1].copy_(self._loss)
+        return losses[:n_steps]
+
 
 def flat_parameters(model: Siren):
     """Flat fp32 parameter buffer in the C ABI's layout (a copy; for inference entry points)."""

@@ -42,6 +42,11 @@ def test_contrast_restatement_matches_reference_fixture(golden):
         locs = g[f"c{k}/locs"]
         got = O.calculate_contrast(locs[0], locs[1], locs[2], scale, g[f"c{k}/image"], focus)
         assert np.allclose(got, g[f"c{k}/result"], rtol=1e-12)
+        # the package's own function (host-side, the name master.py imports) on the same reference outputs
+        from types import SimpleNamespace
+        from mri_super_resolution_amd import contrast
+        rec = SimpleNamespace(cancer_loc=tuple(locs[0]), contralateral_loc=tuple(locs[1]), noise=tuple(locs[2]))
+        assert np.allclose(contrast.calculate_contrast(rec, scale, g[f"c{k}/image"], focus), g[f"c{k}/result"], rtol=1e-12)
 
 
 def test_mat5_reader_against_scipy_writer(tmp_path):

@@ -60,8 +60,7 @@ def test_eleven_patients_two_ranks_with_a_gang(golden):
     """2 ranks (gloo, both on the test GPU) on the real 11-volume list: the plan row-shards one 34-slice volume over both
     ranks (a gang) and packs the other ten whole; every rank ends with the same 11 records."""
     vols = _volumes(golden)
-    costs = [float(64 * 64 * v.shape[2]) * 8 for v in vols]
-    plan = inr_dist.plan_fits(costs, 2)
+    plan = drivers.plan_volumes(vols, 8, 2)          # the schedule run_volumes follows (measured step-time table)
     assert len(plan["gangs"]) == 1 and plan["gangs"][0][1] == [0, 1] and vols[plan["gangs"][0][0]].shape[2] == 34
     assert sorted([plan["gangs"][0][0]] + [j for w in plan["whole"] for j in w]) == list(range(11))
     recs0, recs1 = run_ranks(_two_rank_worker, 2, (8,), timeout=600)
@@ -86,8 +85,9 @@ def test_two_gangs_run_side_by_side(golden):
     each matching the single-process fit of its volume."""
     rest = golden("patients_mean_b0.npz")
     vols = [rest["pat76"], rest["pat78"]]
-    plan = inr_dist.plan_fits([float(64 * 64 * 34) * 8] * 2, 4)
+    plan = drivers.plan_volumes(vols, 8, 4)
     assert plan["gangs"] == [(0, [0, 1]), (1, [2, 3])] and all(len(w) == 0 for w in plan["whole"])
+    assert inr_dist.plan_fits([float(64 * 64 * 34) * 8] * 2, 4)["gangs"] == plan["gangs"]      # (the abstract cost model agrees)
     recs = run_ranks(_two_gang_worker, 4, (8,), timeout=600)
     assert all(r == recs[0] for r in recs) and [int(r["job"]) for r in recs[0]] == [0, 1]
     for j, v in enumerate(vols):

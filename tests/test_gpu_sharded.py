@@ -76,6 +76,36 @@ def test_two_rank_fit_with_different_rank_seeds_is_one_network():
     assert O.rel_l2(f0, ref.flat.cpu().numpy()) < 1e-5
 
 
+def _cycle_worker(rank, world):
+    x, t, w = _problem(n=3000, seed=4)
+    n = x.shape[0]
+    lo, hi = (0, 1400) if rank == 0 else (1400, n)
+    g = torch.Generator().manual_seed(9)
+    tg = torch.rand(3, n, generator=g)
+    wt = torch.rand(3, n, generator=g)
+    torch.manual_seed(0)
+    net = inr.Siren(64, 128, 2, 1).cuda()
+    fitter = inr.ShardedSirenFitter(net, global_rows=n, lr=1e-4)
+    losses = fitter.step_cycle(x[lo:hi].cuda(), tg[:, lo:hi].cuda(), 7, wt[:, lo:hi].cuda(), first_acq=2)
+    return losses.cpu().numpy(), fitter.flat.cpu().numpy()
+
+
+def test_two_rank_cycling_acquisitions_match_single_process():
+    """ShardedSirenFitter.step_cycle (master.py:137-148 on a row-sharded fit): target and weight image change every step,
+    each step is local backward + ONE all-reduce + Adam; both replicas follow the single-process inr_siren_fit_cycle run."""
+    x, _, _ = _problem(n=3000, seed=4)
+    g = torch.Generator().manual_seed(9)
+    tg = torch.rand(3, 3000, generator=g)
+    wt = torch.rand(3, 3000, generator=g)
+    torch.manual_seed(0)
+    ref = inr.SirenFitter(inr.Siren(64, 128, 2, 1).cuda(), lr=1e-4)
+    ref_losses = ref.step_cycle(x.cuda(), tg.cuda(), 7, wt.cuda(), first_acq=2).cpu().numpy()
+    (l0, f0), (l1, f1) = run_ranks(_cycle_worker, 2, timeout=240)
+    assert np.array_equal(f0, f1)
+    assert np.allclose(l0, l1) and np.allclose(l0, ref_losses, rtol=1e-5)
+    assert O.rel_l2(f0, ref.flat.cpu().numpy()) < 1e-5
+
+
 def _volumes():
     rng = np.random.default_rng(3)
     gx, gy = np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 20), indexing="ij")

@@ -64,6 +64,22 @@ for fam in ("gemm_hp", "gemm_h3", "gemm_f32"):
         hbm["gemm_avg_hbm_bytes_per_launch"] = hbm[fam + "_avg_hbm_bytes_per_launch"]
         hbm["gemm_family"] = fam
         break
+# per GEMM class of the pre-split path (template arguments: gemm_hp_pkd / pkc / nt kernels <EPI, ..>, EPI 2 = HPE_MUL = input-grad,
+# 0 / 1 / 4 = forward; gemm_hp_kernel<1, 3> = row-contraction parameter gradient)
+import re
+by_class = {}
+for k, d in hbm["kernels"].items():
+    m = re.search(r"gemm_hp_(pkd|pkc|nt)_kernel<(\d+)", k) or re.search(r"gemm_hp_kernel<(\d+), (\d+)", k)
+    if not m:
+        continue
+    if "gemm_hp_kernel<" in k:
+        cls = "gemm_param_grad" if m.group(1) == "1" else ("gemm_input_grad" if m.group(2) == "2" else "gemm_forward")
+    else:
+        cls = "gemm_input_grad" if m.group(2) == "2" else "gemm_forward"
+    e = by_class.setdefault(cls, [0.0, 0])
+    e[0] += (d.get("fetch_bytes", 0) + d.get("write_bytes", 0)) * d["dispatches"]
+    e[1] += d["dispatches"]
+hbm["hbm_bytes_per_launch_by_class"] = {c: b / n for c, (b, n) in by_class.items() if n}
 json.dump(hbm, open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 sq = {"note": "rocprofv3 --pmc (SQ/GRBM pass) on the same command; per-dispatch averages.  SQ_WAVE/WAIT/ACTIVE count quad-cycles, "
               "SQ_VALU_MFMA_BUSY_CYCLES = MFMA pipe cycles summed over the 1024 SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs.",
@@ -81,7 +97,7 @@ for k, d in sq["kernels"].items():
         print(k[:70], "MFMA util %.3f  bank conflicts %.3g" % (d.get("mfma_pipe_utilisation", 0), d.get("SQ_LDS_BANK_CONFLICT", 0)))
 
 # the full bench line of the round and the RAMS forward summaries, when present
-final = os.path.join(root, "gpurun_out", "r2_bench_final.log")
+final = os.path.join(root, "gpurun_out", f"{tag}_bench_final.log")
 if os.path.exists(final):
     lines = [l for l in open(final) if l.startswith("{")]
     if lines:
