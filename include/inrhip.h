@@ -339,6 +339,16 @@ int inr_rams_shift_loss_grad(double* loss, float* grad_pred, const float* y_true
 int inr_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n_voxels,
                    void* stream);
 
+/* AutoERD acceptance weights -- the per-pixel outlier rejection master.py runs before a 2-D fit (master.py:77-93).
+ * values: [n_pixels][n_acquisitions] fp64 (every acquisition of the slice at that pixel); accept: same shape, fp32, 1 = keep,
+ * 0 = reject.  Each pixel's sample is split in two exactly as sklearn.cluster.AgglomerativeClustering(n_clusters=2,
+ * affinity='euclidean', linkage='complete') splits it (scipy's nearest-neighbour chain + stable sort: ties fall as they do
+ * there); rule 1 (--erd 1, majority voting): a cluster holding >= 2/3 of the acquisitions rejects the other; rule 2 (--erd 2,
+ * intensity-cognisant): where erd_map (fp32 [n_pixels], nullable = everywhere) is positive, the cluster with the lower mean
+ * is rejected.  2 <= n_acquisitions <= 32. */
+int inr_auto_erd(float* accept, const double* values, const float* erd_map, int64_t n_pixels, int n_acquisitions, int rule,
+                 void* stream);
+
 /* ---- measurement hooks (bench.py roofline): per-kernel-class HIP-event timing on the launch stream.
  * class ids: 0 = GEMM forward (sine layer), 1 = GEMM input-grad, 2 = GEMM param-grad, 3 = other */
 int  inr_prof_enable(int enable);

@@ -127,6 +127,7 @@ SIGNATURES = {
     "inr_rams_shift_loss_grad": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_size_t, c_stream]),
     "inr_hybrid_fit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_stream]),
+    "inr_auto_erd": (C.c_int, [c_f32p, C.c_void_p, c_f32p, C.c_int64, C.c_int, C.c_int, c_stream]),
     "inr_prof_enable": (C.c_int, [C.c_int]),
     "inr_prof_reset": (C.c_int, []),
     "inr_prof_read": (C.c_int, [C.c_int, c_i64p, C.POINTER(C.c_double)]),

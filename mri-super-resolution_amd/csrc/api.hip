@@ -143,6 +143,7 @@ int launch_ssim(double* out, const float* x, const float* y, int nimg, int H, in
                 int use_mask, float mask_thr, double* ws, hipStream_t st);
 int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, int nb, hipStream_t st);
 int launch_rescale_linear(float* out, const float* in, int nimg, int H, int W, int OH, int OW, hipStream_t st);
+int launch_auto_erd(float* accept, const double* values, const float* erd_map, int64_t npix, int n, int rule, hipStream_t st);
 int launch_hybrid_fit(double* params, int* status, int* nfev, double* cost, const double* signals, int64_t n,
                       hipStream_t st);
 void set_hybrid_variant(int v);
@@ -1244,6 +1245,13 @@ int inr_rescale2d_linear(float* out, const float* in, int n_images, int height, 
     INR_REQUIRE((long long)height * width < (1ll << 31) && (long long)out_height * out_width < (1ll << 31), INR_E_INVALID,
                 "inr_rescale2d_linear: image too large");
     return launch_rescale_linear(out, in, n_images, height, width, out_height, out_width, (hipStream_t)stream);
+}
+
+int inr_auto_erd(float* accept, const double* values, const float* erd_map, int64_t n_pixels, int n_acquisitions, int rule,
+                 void* stream) {
+    INR_REQUIRE(accept && values, INR_E_INVALID, "inr_auto_erd: null pointer");
+    INR_REQUIRE(n_pixels >= 0 && n_pixels < (1ll << 37), INR_E_INVALID, "inr_auto_erd: bad pixel count");
+    return launch_auto_erd(accept, values, erd_map, n_pixels, n_acquisitions, rule, (hipStream_t)stream);
 }
 
 // ---- RAMS ------------------------------------------------------------------------------------------------

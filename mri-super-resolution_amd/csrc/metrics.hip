@@ -336,4 +336,141 @@ int launch_adc(float* out, const float* data, const float* bvals, int64_t npix, 
     return 0;
 }
 
+// ---- AutoERD acceptance weights (master.py:77-93) --------------------------------------------------------------------------------
+// Per pixel: the n acquisition values (a 1-D sample) are split in two by complete-linkage agglomeration exactly as
+// sklearn.cluster.AgglomerativeClustering(n_clusters=2, linkage='complete') does it -- scipy's nearest-neighbour-chain walk
+// (scipy/cluster/_hierarchy.pyx: nn_chain, ties resolved by scan order and by preferring the previous chain element), a STABLE
+// sort of the merges by distance, the tree cut at its last merge -- then one of the reference's two rejection rules.  Intensities
+// are often integer-valued, so equal distances are the rule, not the exception: every tie falls as it does in scipy
+// (oracle/erd_oracle.py restates the same steps in NumPy and is pinned against sklearn itself: tests/golden/erd.npz).
+// One thread per pixel, float64 throughout (scipy converts to double); n <= ERD_MAXN values live in private arrays.  The
+// reference runs this as a Python double loop over the ROI with one sklearn fit per pixel (3,600 fits per case).
+constexpr int ERD_MAXN = 32;
+
+// numpy's pairwise summation as np.mean runs it on a short contiguous float64 array (n < 8: plain loop; else eight partial sums)
+__device__ double erd_numpy_sum(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__global__ void __launch_bounds__(64) auto_erd_kernel(float* __restrict__ accept, const double* __restrict__ values,
+                                                      const float* __restrict__ erd_map, int64_t npix, int n, int rule,
+                                                      double majority) {
+    const int64_t pix = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (pix >= npix) return;
+    double x[ERD_MAXN], D[ERD_MAXN][ERD_MAXN], md[ERD_MAXN];
+    int size[ERD_MAXN], chain[ERD_MAXN], mlo[ERD_MAXN], mhi[ERD_MAXN], order[ERD_MAXN], parent[ERD_MAXN];
+    for (int i = 0; i < n; ++i) x[i] = values[pix * n + i];
+    for (int i = 0; i < n; ++i) {
+        size[i] = 1;
+        for (int j = 0; j < n; ++j) D[i][j] = fabs(x[i] - x[j]);
+    }
+    int chain_len = 0;
+    for (int k = 0; k < n - 1; ++k) {
+        if (chain_len == 0) {
+            chain_len = 1;
+            for (int i = 0; i < n; ++i)
+                if (size[i] > 0) {
+                    chain[0] = i;
+                    break;
+                }
+        }
+        int a, b;
+        double cur;
+        while (true) {
+            a = chain[chain_len - 1];
+            if (chain_len > 1) {
+                b = chain[chain_len - 2];
+                cur = D[a][b];
+            } else {
+                b = -1;
+                cur = INFINITY;
+            }
+            for (int i = 0; i < n; ++i) {
+                if (size[i] == 0 || i == a) continue;
+                if (D[a][i] < cur) {
+                    cur = D[a][i];
+                    b = i;
+                }
+            }
+            if (chain_len > 1 && b == chain[chain_len - 2]) break;
+            chain[chain_len++] = b;
+        }
+        chain_len -= 2;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        mlo[k] = lo;
+        mhi[k] = hi;
+        md[k] = cur;
+        size[hi] += size[lo];
+        size[lo] = 0;
+        for (int i = 0; i < n; ++i) {
+            if (size[i] == 0 || i == hi) continue;
+            const double d = fmax(D[i][lo], D[i][hi]);
+            D[i][hi] = d;
+            D[hi][i] = d;
+        }
+    }
+    // stable sort of the n - 1 merges by distance (insertion sort keeps equal keys in order)
+    for (int k = 0; k < n - 1; ++k) {
+        int j = k;
+        while (j > 0 && md[order[j - 1]] > md[k]) {
+            order[j] = order[j - 1];
+            --j;
+        }
+        order[j] = k;
+    }
+    for (int i = 0; i < n; ++i) parent[i] = i;
+    auto find = [&](int i) {
+        while (parent[i] != i) i = parent[i];
+        return i;
+    };
+    for (int q = 0; q < n - 2; ++q) {
+        const int k = order[q];
+        parent[find(mlo[k])] = find(mhi[k]);
+    }
+    const int root = find(0);
+    // the two clusters: in0 = with point 0, the rest
+    double g0[ERD_MAXN], g1[ERD_MAXN];
+    int n0 = 0, n1 = 0;
+    bool in0[ERD_MAXN];
+    for (int i = 0; i < n; ++i) {
+        in0[i] = find(i) == root;
+        if (in0[i]) g0[n0++] = x[i];
+        else g1[n1++] = x[i];
+    }
+    bool drop0 = false, drop1 = false;      // reject cluster 0 / cluster 1
+    if (rule == 1) {
+        if ((double)n0 >= majority) drop1 = true;
+        if ((double)n1 >= majority) drop0 = true;
+    } else if (!erd_map || erd_map[pix] > 0.f) {
+        const double m0 = erd_numpy_sum(g0, n0) / (double)n0, m1 = erd_numpy_sum(g1, n1) / (double)n1;
+        if (m0 > m1) drop1 = true;
+        if (m1 > m0) drop0 = true;
+    }
+    for (int i = 0; i < n; ++i) accept[pix * n + i] = (in0[i] ? drop0 : drop1) ? 0.f : 1.f;
+}
+
+int launch_auto_erd(float* accept, const double* values, const float* erd_map, int64_t npix, int n, int rule, hipStream_t st) {
+    INR_REQUIRE(n >= 2 && n <= ERD_MAXN, INR_E_INVALID, "inr_auto_erd: 2 <= acquisitions <= %d (got %d)", ERD_MAXN, n);
+    INR_REQUIRE(rule == 1 || rule == 2, INR_E_INVALID, "inr_auto_erd: rule must be 1 (majority voting) or 2 (intensity-cognisant)");
+    if (npix == 0) return 0;
+    const double majority = (2.0 / 3.0) * (double)n;     // master.py:86, evaluated as Python does
+    ProfScope ps(KC_OTHER, st);
+    hipLaunchKernelGGL(auto_erd_kernel, dim3((unsigned)((npix + 63) / 64)), dim3(64), 0, st, accept, values, erd_map, npix, n, rule,
+                       majority);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace inr

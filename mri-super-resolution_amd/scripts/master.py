@@ -24,7 +24,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(_HERE)))
-from mri_super_resolution_amd import baselines, contrast, drivers, matio, reports  # noqa: E402
+from mri_super_resolution_amd import baselines, contrast, drivers, erd, matio, reports  # noqa: E402
 from mri_super_resolution_amd.contrast import calc_adc, calculate_contrast, minmax_normalize  # noqa: E402
 
 
@@ -78,9 +78,6 @@ def apply_experiment(args, exp):
 
 
 def run(args, cases):
-    if args.erd:
-        raise NotImplementedError("--erd 1/2 (AgglomerativeClustering outlier rejection, master.py:79-93) is outside this "
-                                  "build's scope (SURVEY.md 2); pre-compute case.accept and pass --erd 0")
     os.makedirs(args.out_folder, exist_ok=True)
     csv = reports.ContrastCsv(os.path.join(args.out_folder, args.exp_name + '.csv'))
     directions = ['x', 'y', 'z']
@@ -94,6 +91,9 @@ def run(args, cases):
             r1 = args.ROI_end if args.ROI_end is not None else min(case.dwi.shape[:2])
             b0 = np.asarray(case.b0[r0:r1, r0:r1, _slice], np.float64)
             pt_no = case.pt_id.split('-')[-1]
+            if args.erd:      # master.py:77-93: per-pixel two-cluster outlier rejection -> case.accept (one device launch)
+                print('Conducting Auto-ERD with Agglomerative Clustering...')
+                erd.apply_auto_erd(case, args.erd, r0, r1)
             contrast_fn = lambda im: calculate_contrast(case, 1, im, r0)
             acc = {}
             for direction in range(3):
