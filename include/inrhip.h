@@ -372,7 +372,8 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * (8 = 8 waves x 1 tile, default; 4 = 4 waves x 2 tiles; 16 = two-pass 8 waves x 2 tiles); key 16 = last sine layer of a
  * fit step stashes z only (1 default, 0 = act + omega cos); key 17 = poll limit of the small-network kernel's grid barrier (0 = built-in 2^22;
  * tests force the abandon path with 1); key 18 = 64-row tiles for GEMM launches with too few 128-row tiles to fill the chip
- * (1 default); keys 8/9 = time-stamp selection of diagnostic builds.
+ * (1 default); key 19 = cross-layer fused forward for inr_siren_forward / inr_siren_reconstruct (0 default = one launch per layer; 1 =
+ * all layers of a 64-row panel in one launch: correct, measured slower, kept as a study -- DESIGN.md); keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */
 int inr_debug_get(int key, int* value);    /* the value a key currently holds */
@@ -392,8 +393,9 @@ int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffe
 #define INR_LF_F32_GENERIC 7   /* gemm_f32_kernel: guarded generic kernel */
 #define INR_LF_SMALL_MULTI 8   /* siren_small_multi_kernel: persistent cooperative small-network fit */
 #define INR_LF_SMALL_STEP  9   /* small-network step kernel + reduce/Adam kernel */
-#define INR_LF_HP_NARROW   10  /* gemm_hp_pkn_kernel: HL32 operands, persistent grid, 64-row tiles */
-#define INR_LF_COUNT       11
+#define INR_LF_HP_NARROW   10  /* gemm_hp_nt_kernel: HL32 operands, 64 x 128 tiles (launches too small for the wide tiles) */
+#define INR_LF_HP_FUSED_FWD 11 /* siren_fwd_fused_kernel: every sine layer + the head of a forward in ONE launch, panel in LDS */
+#define INR_LF_COUNT       12
 int inr_launch_count(int family, int64_t* count);
 int inr_launch_counts_reset(void);
 

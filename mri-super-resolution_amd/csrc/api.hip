@@ -87,6 +87,11 @@ int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
                     int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false);
 bool hp_z_stash_ok(int in_f);
+bool hp_fused_forward_ok(int in_f, int hidden, int n_sine);
+int hp_fused_forward(float* y, const char* x_hl, const unsigned* x_amax, int64_t n, int in_f, int hidden, int n_sine,
+                     const char* const* W_hl, const float* const* bias, const unsigned* const* w_amax, float first_omega,
+                     float hidden_omega, const float* head_W, const float* head_b, int use_clamp, float clamp_min,
+                     hipStream_t stream);
 extern tune_int g_hp_zhead;
 int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
@@ -189,7 +194,7 @@ static tune_int g_hp{1};  // pre-split (HL32) GEMM path inside the fused entry p
 extern char* g_h3_scratch;
 extern unsigned long long* g_stamps;
 extern tune_int g_stamp_class, g_stamp_nth;
-extern tune_int g_hp_persistent, g_hp_stagger, g_hp_narrow;
+extern tune_int g_hp_persistent, g_hp_stagger, g_hp_narrow, g_hp_fused_fwd;
 
 // ---- shared helpers ---------------------------------------------------------------------------------
 static const int64_t MAX_ROWS = (1ll << 31) - 256;
@@ -619,6 +624,20 @@ static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const 
     if (h3 && h3->on && xhl) {   // pre-split path: every activation lives in HBM as HL32 (gemm_hp.inc)
         const HpNet net{h3, &L};
         if (int rc = hp_convert(xhl, x, n, L.fan_in[0], net.x_scale(), st)) return rc;
+        if (hp_fused_forward_ok(L.fan_in[0], d->hidden_features, L.n_sine)) {
+            // every sine layer and the head in ONE launch, the activations of a 64-row panel never leaving LDS (gemm_hp_fwd.inc)
+            const char* W[8];
+            const float* bias[8];
+            const unsigned* wmax[8];
+            for (int l = 0; l < L.n_sine; ++l) {
+                W[l] = net.w_hl(l);
+                bias[l] = params + L.b_off[l];
+                wmax[l] = h3->slots + l;
+            }
+            return hp_fused_forward(y, xhl, h3->slots + 24, n, L.fan_in[0], d->hidden_features, L.n_sine, W, bias, wmax,
+                                    d->first_omega, d->hidden_omega, params + L.w_off[L.n_sine], params + L.b_off[L.n_sine],
+                                    use_clamp, clamp_min, st);
+        }
         const char* in = xhl;
         for (int l = 0; l < L.n_sine; ++l) {
             char* dst = reinterpret_cast<char*>(bufs[l & 1]);
@@ -1402,6 +1421,7 @@ const DebugKey* debug_table(int* count) {
         {10, &g_hp_persistent, 2, 0, 2},  {11, &g_hp_stagger, 0, 0, 1 << 20}, {12, &g_small_multi, 1, 0, 1},
         {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 8, 4, 16},
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
+        {19, &g_hp_fused_fwd, 0, 0, 1},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -82,8 +82,9 @@ enum LaunchFamily {
     LF_F32_GENERIC = 7, // gemm_f32_kernel
     LF_SMALL_MULTI = 8, // siren_small_multi_kernel (persistent cooperative)
     LF_SMALL_STEP = 9,  // siren_small step kernel pair
-    LF_HP_NARROW = 10,  // gemm_hp_pkn_kernel   persistent 64-row tiles (few-row launches)
-    LF_COUNT = 11
+    LF_HP_NARROW = 10,  // gemm_hp_nt_kernel    64 x 128 tiles (launches that cannot fill the chip with wide tiles)
+    LF_HP_FUSED_FWD = 11,   // siren_fwd_fused_kernel: all sine layers + head of an inference forward in one launch
+    LF_COUNT = 12
 };
 void count_launch(int family);
 #define INR_E_FALLBACK (-100)   // internal: the chosen kernel cannot run on this device, the caller takes its next-best path

@@ -813,6 +813,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const Gemm
 #include "gemm_h3.inc"
 #include "gemm_hp.inc"
 #include "gemm_hp_nt.inc"
+#include "gemm_hp_fwd.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
 tune_int g_stamp_class{-1}, g_stamp_nth{0}; // hp kernels: which launch receives g_stamps (class, countdown)
@@ -1177,6 +1178,8 @@ static int hp_check_grid(const HpParams& p) {
 // act (HL32 [n][out_f]) = sin(omega (x W^T + b)); dact (fp32, nullable) = omega cos(.)
 // may the last sine layer of a fit step stash z only (HPE_Z)?  (deferred-epilogue kernel shapes; debug key 16)
 tune_int g_hp_zhead{1};
+tune_int g_hp_fused_fwd{0};   // inr_debug_set(19, 1): inference forwards of eligible networks run all layers in one launch (gemm_hp_fwd.inc:
+                              // measured SLOWER than the layer-wise launches at hidden = 512 -- 117 against 144 M voxels/s -- so off by default)
 tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
 bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
 
@@ -1321,6 +1324,39 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
         p.stamps = nullptr;
         return hp_launch_narrow<HPE_MUL>(p, plan.wide_rows, plan.narrow_rows, g_hp_persistent == 2 && out_f == 512, stream);
     }
+    return 0;
+}
+
+// ---- cross-layer fused forward (gemm_hp_fwd.inc) ---------------------------------------------------------------------------
+bool hp_fused_forward_ok(int in_f, int hidden, int n_sine) {
+    return g_hp_fused_fwd && (hidden == 512 || hidden == 256) && in_f % 32 == 0 && in_f >= 32 && in_f <= hidden && n_sine >= 1 &&
+           n_sine <= FW_MAX_LAYERS;
+}
+// y [n] = head(sine layers(x)); x_hl: HL32 image of the network input; W_hl[l] / bias[l] / w_amax[l] per sine layer
+int hp_fused_forward(float* y, const char* x_hl, const unsigned* x_amax, int64_t n, int in_f, int hidden, int n_sine,
+                     const char* const* W_hl, const float* const* bias, const unsigned* const* w_amax, float first_omega,
+                     float hidden_omega, const float* head_W, const float* head_b, int use_clamp, float clamp_min,
+                     hipStream_t stream) {
+    INR_REQUIRE(hp_fused_forward_ok(in_f, hidden, n_sine), INR_E_INVALID, "hp_fused_forward: unsupported network");
+    FwParams p{};
+    for (int l = 0; l < n_sine; ++l) {
+        p.layer[l].W = W_hl[l];
+        p.layer[l].bias = bias[l];
+        p.layer[l].w_amax = w_amax[l];
+        p.layer[l].K = l == 0 ? in_f : hidden;
+        p.layer[l].omega = l == 0 ? first_omega : hidden_omega;
+    }
+    p.n_sine = n_sine; p.H = hidden;
+    p.x = x_hl; p.x_amax = x_amax; p.n = n;
+    p.head_W = head_W; p.head_b = head_b; p.y = y;
+    p.use_clamp = use_clamp; p.clamp_min = clamp_min;
+    const long long panels = (n + FW_ROWS - 1) / FW_ROWS;
+    const dim3 grid((unsigned)(panels < hp_num_cus() ? panels : hp_num_cus())), block(FW_NTH);
+    ProfScope ps(KC_GEMM_FWD, stream);
+    if (hidden == 512) hipLaunchKernelGGL((siren_fwd_fused_kernel<4>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((siren_fwd_fused_kernel<2>), grid, block, 0, stream, p);
+    INR_LAUNCH_CHECK();
+    count_launch(LF_HP_FUSED_FWD);
     return 0;
 }
 

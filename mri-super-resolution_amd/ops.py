@@ -459,7 +459,7 @@ def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_tot
 
 # ---- diagnostics ------------------------------------------------------------------------------------------
 LAUNCH_FAMILIES = ("hp_pkd", "hp_pkc", "hp_tile", "hp_rc", "h3", "f32_pipe16", "f32_pipe", "f32_generic", "small_multi",
-                   "small_step", "hp_narrow")   # INR_LF_* of include/inrhip.h, in order
+                   "small_step", "hp_narrow", "hp_fused_fwd")   # INR_LF_* of include/inrhip.h, in order
 
 
 def launch_counts() -> dict:

@@ -61,6 +61,7 @@ def oracle_loss_grads(ref, x, t, w):
 
 
 def fused_loss_grads(net, x, t, w):
+    """loss, gradients and the (layer-wise) forward"""
     desc, flat = inr.flat_parameters(net)
     grads = torch.zeros_like(flat)
     loss = torch.zeros(1, device="cuda")
@@ -371,3 +372,48 @@ def test_late_training_state(golden):
             runs[exact] = (host(fitter.step(x, t, 20)).copy(), host(fitter.flat).copy())
     assert np.isfinite(runs[False][0]).all()
     assert O.rel_l2(runs[False][1], runs[True][1]) < 1e-4
+
+
+# ------------------------------------------------------------------ cross-layer fused forward (gemm_hp_fwd.inc) -------------
+@pytest.mark.parametrize("fin,hidden,layers,n", [(256, 512, 3, 4099), (256, 512, 3, 1), (32, 512, 0, 63), (512, 512, 7, 64),
+                                                  (64, 256, 2, 65), (256, 256, 5, 1000), (96, 256, 1, 130), (160, 512, 2, 20000)])
+def test_fused_forward_all_layers_in_one_launch(fin, hidden, layers, n):
+    """inr_debug_set(19, 1): inr_siren_forward of an eligible network as ONE launch (siren_fwd_fused_kernel: a 64-row panel walks
+    through every sine layer and the head inside LDS), against the float64 oracle (T1) and against the layer-wise launches (same
+    arithmetic; only the head's fp32 row sum is grouped differently).  Measured slower than those at hidden = 512, so not the
+    default (cross-layer fusion study) -- but it must stay right."""
+    net, ref = make_pair(fin, hidden, layers, seed=fin + layers)
+    net.cuda()
+    x = torch.rand(n, fin, generator=torch.Generator().manual_seed(n)) * 2 - 1
+    want = ref(x.double()).detach().numpy()
+    desc, flat = inr.flat_parameters(net)
+    xd = x.cuda()
+    ops.launch_counts_reset()
+    y_layers = host(ops.siren_forward(desc, flat, xd))
+    assert ops.launch_counts()["hp_fused_fwd"] == 0
+    with ops.debug_switch(19, 1):
+        ops.launch_counts_reset()
+        y = host(ops.siren_forward(desc, flat, xd))
+        c = ops.launch_counts()
+        assert c["hp_fused_fwd"] == 1 and c["hp_pkd"] + c["hp_pkc"] + c["hp_tile"] + c["hp_narrow"] + c["f32_pipe16"] == 0, c
+        yc = host(ops.siren_forward(desc, flat, xd, clamp_min=0.05))
+        part = host(ops.siren_forward(desc, flat, xd[37:n - 5].contiguous())) if n > 70 else None
+    assert y.shape == (n, 1) and O.rel_l2(y, want) < T1
+    assert O.rel_l2(y, y_layers) < 2e-6 and np.abs(y - y_layers).max() < 2e-6
+    assert np.array_equal(yc, np.maximum(y, np.float32(0.05)))
+    if part is not None:                                      # a row's value depends on nothing but the row
+        assert np.array_equal(part, y[37:n - 5])
+
+
+def test_fused_forward_falls_back_where_the_panel_does_not_fit():
+    """hidden = 1024 (a 256 KB panel) and in_features > hidden keep the layer-wise launches."""
+    for fin, hidden in ((64, 1024), (512, 256)):
+        net, ref = make_pair(fin, hidden, 1, seed=3)
+        net.cuda()
+        x = torch.rand(300, fin) * 2 - 1
+        desc, flat = inr.flat_parameters(net)
+        with ops.debug_switch(19, 1):
+            ops.launch_counts_reset()
+            y = host(ops.siren_forward(desc, flat, x.cuda()))
+            assert ops.launch_counts()["hp_fused_fwd"] == 0
+        assert O.rel_l2(y, ref(x.double()).detach().numpy()) < T1
