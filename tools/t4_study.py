@@ -53,7 +53,7 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "pat07_slice11.npz"))
     ref = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_ref_psnr.npz"))
     seeds = [int(s) for s in ref["seeds"]][:int(sys.argv[2]) if len(sys.argv) > 2 else None]
-    hr, lr = g["hr"].astype(np.float32), g["lr"].astype(np.float32)
+    hr, lr = np.ascontiguousarray(g["hr"], np.float32), np.ascontiguousarray(g["lr"], np.float32)
     hr_t = torch.from_numpy(hr).cuda()
     ref_final = {int(s): float(p) for s, p in zip(ref["seeds"], ref["psnr_db"])}
     ref_trace = {int(s): np.append(t, p) for s, t, p in zip(ref["seeds"], ref["trace_db"], ref["psnr_db"])
