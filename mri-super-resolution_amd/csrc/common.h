@@ -108,6 +108,7 @@ struct FinalizeSeg {
 struct FinalizeJob {
     FinalizeSeg seg[FIN_MAX_SEG];
     long long first[FIN_MAX_SEG + 1];   // prefix sums of len
+    long long s1_first[FIN_MAX_SEG + 1];   // prefix sums of the first-stage blocks per segment (0 for stacks that need none)
     int nseg;
     const float* part_loss;             // [nparts] per-block loss terms (nullable)
     int nparts;

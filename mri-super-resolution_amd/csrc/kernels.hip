@@ -356,12 +356,17 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ o
 }
 
 // ---- deferred reduction + loss + Adam of a fused step (common.h: FinalizeJob) ---------------------------------------------
-// first stage for tall slab stacks: grid (ceil(max len / 256), max groups, segments)
+// first stage for tall slab stacks: one block per (segment, group of FIN_GROUP rows, 256 columns), numbered through the
+// prefix table job.s1_first -- no empty blocks (a dense 3-D grid over the maxima launched 21 M of them at 4 M rows: 5 ms)
 __global__ void __launch_bounds__(256) finalize_stage1_kernel(const FinalizeJob job) {
-    const FinalizeSeg sg = job.seg[blockIdx.z];
-    if (sg.nslabs <= FIN_TALL) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int s0 = blockIdx.y * FIN_GROUP;
+    int k = 0;
+    while ((long long)blockIdx.x >= job.s1_first[k + 1]) ++k;
+    const FinalizeSeg sg = job.seg[k];
+    const long long local = (long long)blockIdx.x - job.s1_first[k];
+    const long long gx = (sg.len + 255) / 256;
+    const int64_t i = (local % gx) * 256 + threadIdx.x;
+    const int group = (int)(local / gx);
+    const int s0 = group * FIN_GROUP;
     if (i >= sg.len || s0 >= sg.nslabs) return;
     const int s1 = min(sg.nslabs, s0 + FIN_GROUP);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(256) finalize_stage1_kernel(const FinalizeJob 
         a3 += sg.slab[(int64_t)(s + 3) * sg.len + i];
     }
     for (; s < s1; ++s) a0 += sg.slab[(int64_t)s * sg.len + i];
-    sg.stage1[(int64_t)blockIdx.y * sg.len + i] = (a0 + a1) + (a2 + a3);
+    sg.stage1[(int64_t)group * sg.len + i] = (a0 + a1) + (a2 + a3);
 }
 
 // one thread per gradient element: fixed-order sum of its slab column, gradient out, Adam step (torch's single-tensor
@@ -655,17 +660,17 @@ int launch_finish_sum(float* out, const float* partial, int nparts, float scale,
 int launch_finalize(FinalizeJob& job, long long adam_step, double lr, double b1, double b2, double eps, hipStream_t st) {
     INR_REQUIRE(job.nseg >= 1 && job.nseg <= FIN_MAX_SEG, INR_E_INVALID, "finalize: %d segments", job.nseg);
     job.first[0] = 0;
-    long long max_len = 0;
-    int max_groups = 0;
+    job.s1_first[0] = 0;
     for (int k = 0; k < job.nseg; ++k) {
         job.first[k + 1] = job.first[k] + job.seg[k].len;
+        long long blocks = 0;
         if (job.seg[k].nslabs > FIN_TALL) {
             INR_REQUIRE(job.seg[k].stage1 != nullptr, INR_E_INVALID, "finalize: tall segment %d without a first-stage buffer", k);
-            if (job.seg[k].len > max_len) max_len = job.seg[k].len;
-            const int g = (job.seg[k].nslabs + FIN_GROUP - 1) / FIN_GROUP;
-            if (g > max_groups) max_groups = g;
+            blocks = ((job.seg[k].len + 255) / 256) * ((job.seg[k].nslabs + FIN_GROUP - 1) / FIN_GROUP);
         }
+        job.s1_first[k + 1] = job.s1_first[k] + blocks;
     }
+    const long long s1_blocks = job.s1_first[job.nseg];
     if (job.params) {
         const double bc1 = 1.0 - pow(b1, (double)adam_step), bc2 = 1.0 - pow(b2, (double)adam_step);
         job.one_minus_b1 = (float)(1.0 - b1);
@@ -676,10 +681,9 @@ int launch_finalize(FinalizeJob& job, long long adam_step, double lr, double b1,
         job.eps = (float)eps;
     }
     ProfScope ps(KC_OTHER, st);
-    if (max_groups > 0) {
-        INR_REQUIRE(max_groups <= 65535, INR_E_INVALID, "finalize: slab stack too tall (%d groups)", max_groups);
-        hipLaunchKernelGGL(finalize_stage1_kernel, dim3((unsigned)((max_len + 255) / 256), (unsigned)max_groups, (unsigned)job.nseg),
-                           dim3(256), 0, st, job);
+    if (s1_blocks > 0) {
+        INR_REQUIRE(s1_blocks < (1ll << 31), INR_E_INVALID, "finalize: too many first-stage blocks (%lld)", s1_blocks);
+        hipLaunchKernelGGL(finalize_stage1_kernel, dim3((unsigned)s1_blocks), dim3(256), 0, st, job);
         INR_LAUNCH_CHECK();
     }
     const long long blocks = (job.first[job.nseg] + 255) / 256 + 1;   // + the loss block
