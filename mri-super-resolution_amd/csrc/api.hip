@@ -87,6 +87,9 @@ int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
                     int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false);
 bool hp_z_stash_ok(int in_f);
+bool hp_grid_fourier_ok(int m, int dim);
+int hp_grid_fourier_hl(char* x_hl, unsigned* x_amax, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, const float* B,
+                       int m, hipStream_t stream);
 bool hp_fused_forward_ok(int in_f, int hidden, int n_sine);
 int hp_fused_forward(float* y, const char* x_hl, const unsigned* x_amax, int64_t n, int in_f, int hidden, int n_sine,
                      const char* const* W_hl, const float* const* bias, const unsigned* const* w_amax, float first_omega,
@@ -615,15 +618,18 @@ size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n
 
 static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const float* params, const float* x,
                               int64_t n, float* y, int use_clamp, float clamp_min, float* buf0, float* buf1,
-                              hipStream_t st, const H3Ctx* h3 = nullptr, char* xhl = nullptr) {
+                              hipStream_t st, const H3Ctx* h3 = nullptr, char* xhl = nullptr, bool xhl_ready = false) {
+    // xhl_ready: the caller has already written the HL32 image of the input and its scale slot (hp_grid_fourier_hl); x unused
     const float* cur = x;
     float* bufs[2] = {buf0, buf1};
-    if (h3 && h3->on) {
+    if (h3 && h3->on && !xhl_ready) {
         if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
     if (h3 && h3->on && xhl) {   // pre-split path: every activation lives in HBM as HL32 (gemm_hp.inc)
         const HpNet net{h3, &L};
-        if (int rc = hp_convert(xhl, x, n, L.fan_in[0], net.x_scale(), st)) return rc;
+        if (!xhl_ready) {
+            if (int rc = hp_convert(xhl, x, n, L.fan_in[0], net.x_scale(), st)) return rc;
+        }
         if (hp_fused_forward_ok(L.fan_in[0], d->hidden_features, L.n_sine)) {
             // every sine layer and the head in ONE launch, the activations of a 64-row panel never leaving LDS (gemm_hp_fwd.inc)
             const char* W[8];
@@ -740,11 +746,14 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
     }
     for (int64_t r0 = 0; r0 < total; r0 += chunk_rows) {
         const int64_t rows = (total - r0 < chunk_rows) ? (total - r0) : chunk_rows;
-        int rc = B ? launch_fourier(feats, nullptr, shape, dim, r0, rows, B, m, st)
-                   : launch_mgrid(feats, shape, dim, r0, rows, st);
+        // pre-split path with Fourier features: grid -> features -> HL32 image in ONE kernel (no fp32 feature matrix at all)
+        const bool direct = xhl && B && hp_grid_fourier_ok(m, dim);
+        int rc = direct ? hp_grid_fourier_hl(xhl, h3.slots + 24, shape, dim, r0, rows, B, m, st)
+                 : B    ? launch_fourier(feats, nullptr, shape, dim, r0, rows, B, m, st)
+                        : launch_mgrid(feats, shape, dim, r0, rows, st);
         if (rc) return rc;
         rc = siren_forward_impl(desc, L, params, feats, rows, y + r0 * desc->out_features, use_clamp, clamp_min, b0,
-                                b1, st, &h3, xhl);
+                                b1, st, &h3, xhl, direct);
         if (rc) return rc;
     }
     return 0;

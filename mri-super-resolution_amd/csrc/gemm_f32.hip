@@ -1327,6 +1327,73 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
     return 0;
 }
 
+// ---- grid -> Fourier features -> HL32 in one kernel (dense re-sampling) --------------------------------------------------------
+// inr_siren_reconstruct built its network input per chunk in four passes: fourier_kernel (1 KB per voxel written at 256
+// features), tensor_amax (1 KB read), hp_convert (1 KB read, 1 KB written), then layer 0 reads the HL32 image.  Features are
+// sines and cosines, so max|x| <= 1 and the input scale (floor 1.0) is 2^14 whatever the data: here one thread computes
+// eight frequencies of a row exactly as fourier_kernel does (same grid rule, same fma order, same sincos) and writes their
+// sin and cos octets as HL32 directly -- 1 KB written, 1 KB read per voxel, bit-identical operands.  Needs m % 32 == 0.
+struct HlGrid {
+    int dim;
+    long long n[8];
+};
+__global__ void __launch_bounds__(256) grid_fourier_hl_kernel(char* __restrict__ out, HlGrid g, long long row_begin, long long n_rows,
+                                                              const float* __restrict__ B, int m, unsigned* __restrict__ x_amax) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) *x_amax = 0x3f800000u;                       // max(1, max|x|) = 1: what tensor_amax would have found
+    const int per_row = m >> 3;
+    if (t >= n_rows * per_row) return;
+    const long long row = t / per_row;
+    const int j0 = (int)(t - row * per_row) * 8;
+    const float two_pi = 6.283185307179586f;
+    long long rem = row_begin + row;
+    float c[8];
+#pragma unroll
+    for (int a = 7; a >= 0; --a) {
+        if (a < g.dim) {
+            const long long idx = rem % g.n[a];
+            rem /= g.n[a];
+            c[a] = linspace_pm1(idx, g.n[a]);
+        }
+    }
+    float sv[8], cv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float proj = 0.f;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+            if (a < g.dim) proj = fmaf(two_pi * c[a], B[(j0 + e) * g.dim + a], proj);
+        sincos_f32(proj, sv[e], cv[e]);
+    }
+    const float s = h3_pow2(14);
+    u32x4 hi, lo;
+    const int cols = 2 * m;
+    hp_split8(sv, s, hi, lo);
+    char* dst = out + hp_off(row, j0, cols);
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 64) = lo;
+    hp_split8(cv, s, hi, lo);
+    dst = out + hp_off(row, m + j0, cols);
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 64) = lo;
+}
+
+bool hp_grid_fourier_ok(int m, int dim) { return m >= 32 && m % 32 == 0 && dim >= 1 && dim <= 8; }
+int hp_grid_fourier_hl(char* x_hl, unsigned* x_amax, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, const float* B,
+                       int m, hipStream_t stream) {
+    INR_REQUIRE(hp_grid_fourier_ok(m, dim), INR_E_INVALID, "hp_grid_fourier_hl: m = %d, dim = %d", m, dim);
+    if (n_rows == 0) return 0;
+    HlGrid g{};
+    g.dim = dim;
+    for (int a = 0; a < 8; ++a) g.n[a] = a < dim ? shape[a] : 1;
+    const long long work = n_rows * (m >> 3);
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(grid_fourier_hl_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, stream, x_hl, g, (long long)row_begin,
+                       (long long)n_rows, B, m, x_amax);
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- cross-layer fused forward (gemm_hp_fwd.inc) ---------------------------------------------------------------------------
 bool hp_fused_forward_ok(int in_f, int hidden, int n_sine) {
     return g_hp_fused_fwd && (hidden == 512 || hidden == 256) && in_f % 32 == 0 && in_f >= 32 && in_f <= hidden && n_sine >= 1 &&

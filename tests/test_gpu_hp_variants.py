@@ -417,3 +417,23 @@ def test_fused_forward_falls_back_where_the_panel_does_not_fit():
             y = host(ops.siren_forward(desc, flat, x.cuda()))
             assert ops.launch_counts()["hp_fused_fwd"] == 0
         assert O.rel_l2(y, ref(x.double()).detach().numpy()) < T1
+
+
+@pytest.mark.parametrize("shape,m,hidden", [((40, 33), 128, 512), ((9, 10, 7), 32, 256), ((5, 6, 3, 4), 64, 128), ((31, 17), 16, 128)])
+def test_reconstruct_builds_its_input_as_hl32_directly(shape, m, hidden):
+    """inr_siren_reconstruct on the pre-split path: grid -> Fourier features -> HL32 operand image in ONE kernel per chunk
+    (no fp32 feature matrix, no amax pass, no conversion pass) -- bit for bit what the explicit get_mgrid -> input_mapping ->
+    inr_siren_forward sequence gives, in any chunking; m % 32 != 0 keeps the three-pass form."""
+    torch.manual_seed(m)
+    net = inr.Siren(2 * m, hidden, 2, 1).cuda()
+    B = torch.from_numpy(P.fourier_matrix(len(shape), mapping_size=m, seed=5)).cuda()
+    desc, flat = inr.flat_parameters(net)
+    x = inr.input_mapping(inr.get_mgrid(shape), B)
+    want = host(ops.siren_forward(desc, flat, x, clamp_min=0.0)).reshape(shape)
+    got = host(inr.reconstruct(net, shape, B))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    small = host(inr.reconstruct(net, shape, B, chunk_rows=101))
+    assert np.array_equal(small.view(np.uint32), got.view(np.uint32))
+    ref = P.PortSiren(2 * m, hidden, 2, 1)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=False)
+    assert O.rel_l2(got, P.port_reconstruct(ref, shape, B.cpu())) < T1
