@@ -13,7 +13,10 @@
  *    void* (0 = the null stream).  No torch types, no ownership transfer: the caller allocates every
  *    output and every workspace (size from the matching *_workspace_bytes query).
  *  - every function only ENQUEUES work on `stream` and returns without synchronising (graph-capture
- *    safe: no allocation, no host sync inside).  ONE exception: when inr_siren_fit / inr_siren_fit_cycle
+ *    safe: no allocation, no host sync inside; the fused fit forks its parameter-gradient GEMMs onto one
+ *    library-owned non-blocking stream per device -- created on first use -- and joins it back into
+ *    `stream` by events before it returns: everything the call enqueued is ordered before whatever the
+ *    caller enqueues on `stream` next).  ONE exception: when inr_siren_fit / inr_siren_fit_cycle
  *    take the persistent cooperative small-network kernel (hidden 32 / 64, <= 32 input features, one
  *    output, few thousand rows) they wait for the stream once at the end of the call to read the
  *    kernel's completion word, and return INR_E_TIMEOUT if a launch was abandoned (cooperative launches
@@ -223,9 +226,18 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
  * The mean of the loss runs over count_total elements (0 = n*out_features, i.e. an unsplit fit), so gradients and
  * losses of the shards add up to the full-batch step: all-reduce(sum) `grads` (flat, inr_siren_param_count floats)
  * and `loss`, then call inr_adam_step on every rank.  Workspace: inr_siren_fit_workspace_bytes(desc, n). */
+#define INR_REUSE_INPUT_IMAGE  1   /* x, n and `workspace` are those of the previous call on this workspace: keep the
+                                      operand image of x and its scale (skips two passes over x per call) */
+#define INR_REUSE_TARGET_STATS 2   /* target / weight are those of the previous call: keep their maxima */
 int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
                         const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* the same with `flags` (INR_REUSE_*): a fit whose rows are split over GPUs calls this once per step on unchanged inputs --
+ * without the flags every call re-measures and re-converts x (0.25 ms at 524,288 rows x 256 features).  The caller vouches for
+ * "unchanged": same x contents, same n, same workspace, nothing else written to it in between. */
+int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
+                        const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
+                        void* workspace, size_t workspace_bytes, int flags, void* stream);
 
 /* ---- a-12: end-of-fit metrics on the device (fp64 accumulation, fixed-order reductions) -----------------
  * workspace for all three image metrics: inr_metric_workspace_bytes(n_images).
@@ -373,7 +385,9 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * fit step stashes z only (1 default, 0 = act + omega cos); key 17 = poll limit of the small-network kernel's grid barrier (0 = built-in 2^22;
  * tests force the abandon path with 1); key 18 = 64-row tiles for GEMM launches with too few 128-row tiles to fill the chip
  * (1 default); key 19 = cross-layer fused forward for inr_siren_forward / inr_siren_reconstruct (0 default = one launch per layer; 1 =
- * all layers of a 64-row panel in one launch: correct, measured slower, kept as a study -- DESIGN.md); keys 8/9 = time-stamp selection of diagnostic builds.
+ * all layers of a 64-row panel in one launch: correct, measured slower, kept as a study -- DESIGN.md); key 20 = the parameter-gradient GEMMs of a fused step on an
+ * internal side stream, forked and joined by events around each layer's input-gradient GEMM (1 default; 0 = in line);
+ * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */
 int inr_debug_get(int key, int* value);    /* the value a key currently holds */

@@ -901,6 +901,33 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
 }
 
 
+// ---- a side stream for the parameter-gradient GEMMs (inr_debug_set(20, 0) puts them back in line) ---------------------------
+// dW_l = dz_l^T act_l and dz_{l-1} = (dz_l W_l) * dact_{l-1} read the same dz_l and write different buffers (the deferred slab
+// regions made that so): they can run side by side -- the ramp-up of one under the drain of the other.  One non-blocking stream
+// and two events per device, created on first use (the only objects the library ever creates; a fork / join of events is
+// graph-capturable).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static int side_stream(SideStream** out) {
+    static std::mutex mu;
+    static SideStream per_device[16];
+    int dev = 0;
+    INR_HIP(hipGetDevice(&dev));
+    INR_REQUIRE(dev >= 0 && dev < 16, INR_E_INVALID, "side stream: device index %d", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    SideStream& s = per_device[dev];
+    if (!s.stream) {
+        INR_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        INR_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        INR_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
+    *out = &s;
+    return 0;
+}
+tune_int g_hp_side_stream{1};   // measured: -2 % per step at 4 k - 70 k rows, nothing at 524 k, identical bits (tools/side_stream_ab.py)
+
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
 // dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
 // here: every producer leaves its slab rows in `slabs` and `fin` describes them (the caller finishes with launch_finalize).
@@ -966,11 +993,21 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         fin.part_loss = part_loss;
         fin.nparts = blocks;
     }
+    SideStream* side = nullptr;
+    if (g_hp_side_stream && L.n_sine > 1) {
+        if (int rc = side_stream(&side)) return rc;
+    }
     for (int l = L.n_sine - 1; l >= 0; --l) {
         const char* dz = reinterpret_cast<const char*>(dact[l]);
         const int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);
+        hipStream_t st_w = st;
+        if (side) {   // dz_l is complete on `st`: the side stream may start dW_l while `st` goes on with dX_l
+            INR_HIP(hipEventRecord(side->fork, st));
+            INR_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+            st_w = side->stream;
+        }
         if (int rc = hp_param_grad_slabs(const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), n, L.fan_in[l],
-                                         L.fan_out[l], dz_scale(l), net.act_scale(l), st))
+                                         L.fan_out[l], dz_scale(l), net.act_scale(l), st_w))
             return rc;
         fin.seg[2 * l].nslabs = splits;
         if (l > 0) {
@@ -982,17 +1019,25 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
             fin.seg[2 * (l - 1) + 1].nslabs = rows;
         }
     }
+    if (side) {   // join: the caller's finalize launch (and the next step's forward) must see every dW slab
+        INR_HIP(hipEventRecord(side->join, side->stream));
+        INR_HIP(hipStreamWaitEvent(st, side->join, 0));
+    }
     return 0;
 }
 
 // per call: scales of the network input and of the targets, HL32 image of x
 static int hp_prepare_call(const H3Ctx& ctx, const Layout& L, char* xhl, const float* x, const float* target,
-                           const float* weight, int64_t n, int out_f, hipStream_t st, int64_t n_acq = 1) {
+                           const float* weight, int64_t n, int out_f, hipStream_t st, int64_t n_acq = 1, bool keep_x = false,
+                           bool keep_stats = false) {
     // (several acquisitions behind one pointer: the bounds cover all of them)
-    if (int rc = h3_tensor_amax(ctx.slots + 25, target, (long long)n * n_acq * out_f, st, 0u)) return rc;
-    if (weight) {
-        if (int rc = h3_tensor_amax(ctx.slots + 26, weight, (long long)n * n_acq * out_f, st, 0u)) return rc;
+    if (!keep_stats) {
+        if (int rc = h3_tensor_amax(ctx.slots + 25, target, (long long)n * n_acq * out_f, st, 0u)) return rc;
+        if (weight) {
+            if (int rc = h3_tensor_amax(ctx.slots + 26, weight, (long long)n * n_acq * out_f, st, 0u)) return rc;
+        }
     }
+    if (keep_x) return 0;     // the HL32 image of x and its scale slot are the previous call's (the caller vouches for it)
     HpScale sx;
     sx.meas = ctx.slots + 24;
     sx.mul = 1.f;
@@ -1103,7 +1148,16 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
 int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
                         const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
                         void* workspace, size_t workspace_bytes, void* stream) {
+    return inr_siren_loss_grad_ex(desc, params, grads, x, target, weight, n, count_total, loss, workspace, workspace_bytes, 0,
+                                  stream);
+}
+
+int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
+                           const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
+                           void* workspace, size_t workspace_bytes, int flags, void* stream) {
     if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE((flags & ~(INR_REUSE_INPUT_IMAGE | INR_REUSE_TARGET_STATS)) == 0, INR_E_INVALID,
+                "inr_siren_loss_grad_ex: unknown flags 0x%x", flags);
     INR_REQUIRE(params && grads && x && target && loss, INR_E_INVALID, "inr_siren_loss_grad: null pointer");
     INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_loss_grad: bad row count %lld", (long long)n);
     INR_REQUIRE(count_total == 0 || count_total >= n * desc->out_features, INR_E_INVALID,
@@ -1125,13 +1179,18 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
     float* gy = (float*)((char*)y + c.out_b);
     float* scratch = (float*)((char*)gy + c.out_b);
     H3Ctx h3;
+    const bool keep_x = (flags & INR_REUSE_INPUT_IMAGE) != 0;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, base + c.h3_off);
-        if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream, 0x3f800000u)) return rc;
+        if (!keep_x) {
+            if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream, 0x3f800000u)) return rc;
+        }
     }
     if (hp_eligible(desc, L)) {
         char* xhl = base + c.xhl_off;
-        if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, (hipStream_t)stream)) return rc;
+        if (int rc = hp_prepare_call(h3, L, xhl, x, target, weight, n, desc->out_features, (hipStream_t)stream, 1, keep_x,
+                                     (flags & INR_REUSE_TARGET_STATS) != 0))
+            return rc;
         FinalizeJob fin;
         if (int rc = fit_forward_backward_hp(desc, L, params, grads, act, dact, xhl, scratch, target, weight, n, count_total, loss,
                                              (hipStream_t)stream, h3, fin))
@@ -1430,7 +1489,7 @@ const DebugKey* debug_table(int* count) {
         {10, &g_hp_persistent, 2, 0, 2},  {11, &g_hp_stagger, 0, 0, 1 << 20}, {12, &g_small_multi, 1, 0, 1},
         {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 8, 4, 16},
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
-        {19, &g_hp_fused_fwd, 0, 0, 1},
+        {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

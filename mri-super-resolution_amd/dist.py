@@ -58,12 +58,12 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
 # (tools/step_time_table.py -> profiles/r03_step_time_table.json).  `fused` = inr_siren_fit (a whole volume on one rank),
 # `sharded` = inr_siren_loss_grad + inr_adam_step per step (what a gang member runs between two all-reduces).  A step is not
 # linear in the rows: ~0.15 ms of it is fixed (kernel ramp-up / drain of ~16 launches), which is what makes row-sharding cost
-# GPU time -- three 46,421-row shards take 3 x 0.97 = 2.9 ms where the whole 139,264-row volume takes 2.42.
+# GPU time -- three 46,421-row shards take 3 x 0.91 = 2.7 ms where the whole 139,264-row volume takes 2.40.
 STEP_TIME_TABLE_MS = (
     # rows, fused, sharded
-    (4096, 0.2166, 0.2802), (16384, 0.4577, 0.5214), (32768, 0.6791, 0.7537), (46421, 0.8898, 0.9700), (65536, 1.1925, 1.2782),
-    (69632, 1.3243, 1.4166), (98304, 1.7211, 1.8129), (114688, 1.9860, 2.0741), (139264, 2.4223, 2.5241), (262144, 4.4010, 4.5508),
-    (524288, 8.6920, 8.9444),
+    (4096, 0.2163, 0.2210), (16384, 0.4829, 0.4881), (32768, 0.6897, 0.6965), (46421, 0.9017, 0.9054), (65536, 1.2141, 1.2223),
+    (69632, 1.2954, 1.3006), (98304, 1.7289, 1.7346), (114688, 1.9819, 1.9872), (139264, 2.4013, 2.4007), (262144, 4.3988, 4.4011),
+    (524288, 8.6755, 8.6791),
 )
 GRADIENT_BYTES = 3_682_320          # flat fp32 gradient of Siren(256,512,3,1) + the loss slot: one all-reduce per step
 

@@ -433,8 +433,10 @@ class ShardedSirenFitter(SirenFitter):
         losses = torch.empty(max(int(n_steps), 1), dtype=torch.float32, device=x.device)
         count_total = self.global_rows * self.desc.out_features
         for it in range(int(n_steps)):
+            # from the second step of this call on, x / target / weight are unchanged: keep their operand image and maxima
+            flags = (ops.REUSE_INPUT_IMAGE | ops.REUSE_TARGET_STATS) if (it > 0 and self._workspace is not None) else 0
             self._workspace = ops.siren_loss_grad(self.desc, self.flat, self.grads, x, t, w, count_total, self._loss,
-                                                  self._workspace)
+                                                  self._workspace, flags)
             self._all_reduce(self._gbuf)          # gradient + loss in one message
             self.step_count += 1
             ops.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
@@ -460,8 +462,9 @@ class ShardedSirenFitter(SirenFitter):
         count_total = self.global_rows * self.desc.out_features
         for it in range(int(n_steps)):
             a = (int(first_acq) + it) % n_acq
+            flags = ops.REUSE_INPUT_IMAGE if (it > 0 and self._workspace is not None) else 0      # (the targets do change)
             self._workspace = ops.siren_loss_grad(self.desc, self.flat, self.grads, x, t[a], None if w is None else w[a],
-                                                  count_total, self._loss, self._workspace)
+                                                  count_total, self._loss, self._workspace, flags)
             self._all_reduce(self._gbuf)
             self.step_count += 1
             ops.adam_step(self.flat, self.grads, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],

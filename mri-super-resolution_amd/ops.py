@@ -433,8 +433,12 @@ def siren_fit_cycle(desc: SirenDesc, params, grads, m, v, x, targets, weights, f
     return workspace
 
 
-def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_total: int, loss, workspace=None):
-    """Forward + loss + backward of one row shard (no optimizer); see ``inr_siren_loss_grad``."""
+REUSE_INPUT_IMAGE, REUSE_TARGET_STATS = 1, 2        # INR_REUSE_* of include/inrhip.h
+
+
+def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_total: int, loss, workspace=None, flags: int = 0):
+    """Forward + loss + backward of one row shard (no optimizer); see ``inr_siren_loss_grad`` / ``_ex`` (``flags``: the
+    caller vouches that x / the targets are those of the previous call on this workspace)."""
     total, _ = siren_param_layout(desc)
     for name, t in (("params", params), ("grads", grads)):
         _chk(t, name)
@@ -450,10 +454,13 @@ def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_tot
         _chk(weight, "weight")
     need = siren_fit_workspace_bytes(desc, n)
     if workspace is None or workspace.numel() * workspace.element_size() < need:
+        if flags:
+            raise ValueError("REUSE_* flags need the workspace of the previous call")
         workspace = _ws(need, x.device)
-    check(lib().inr_siren_loss_grad(C.byref(desc), params.data_ptr(), grads.data_ptr(), x.data_ptr(), target.data_ptr(),
-                                    _ptr(weight), n, int(count_total), loss.data_ptr(), workspace.data_ptr(),
-                                    workspace.numel() * workspace.element_size(), _stream()), "inr_siren_loss_grad")
+    check(lib().inr_siren_loss_grad_ex(C.byref(desc), params.data_ptr(), grads.data_ptr(), x.data_ptr(), target.data_ptr(),
+                                       _ptr(weight), n, int(count_total), loss.data_ptr(), workspace.data_ptr(),
+                                       workspace.numel() * workspace.element_size(), int(flags), _stream()),
+          "inr_siren_loss_grad_ex")
     return workspace
 
 

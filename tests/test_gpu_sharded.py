@@ -39,6 +39,29 @@ def test_shard_gradients_add_up():
     assert abs(acc_l.item() - full_l.item()) < 1e-6 * full_l.item()
 
 
+def test_loss_grad_reuse_flags_change_nothing():
+    """inr_siren_loss_grad_ex(INR_REUSE_INPUT_IMAGE | INR_REUSE_TARGET_STATS): the second call on unchanged inputs skips the
+    passes over x and the targets and returns the same bits; an unknown flag is refused."""
+    from mri_super_resolution_amd._lib import InrHipError
+    x, t, w = (a.cuda() for a in _problem(n=5000, seed=3))
+    x = torch.cat([x, x, x, x], dim=1).contiguous()              # 256 features: the pre-split path
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 2, 1).cuda()
+    desc, flat = inr.flat_parameters(net)
+    out = []
+    ws = None
+    for flags in (0, 0, ops.REUSE_INPUT_IMAGE | ops.REUSE_TARGET_STATS, ops.REUSE_INPUT_IMAGE):
+        g, l = torch.zeros_like(flat), torch.zeros(1, device="cuda")
+        ws = ops.siren_loss_grad(desc, flat, g, x, t.reshape(-1), w.reshape(-1), 0, l, ws, flags)
+        out.append((g.cpu().numpy().copy(), l.item()))
+    for g, l in out[1:]:
+        assert np.array_equal(g.view(np.uint32), out[0][0].view(np.uint32)) and l == out[0][1]
+    with pytest.raises(InrHipError, match="unknown flags"):
+        ops.siren_loss_grad(desc, flat, torch.zeros_like(flat), x, t.reshape(-1), None, 0, torch.zeros(1, device="cuda"), ws, 8)
+    with pytest.raises(ValueError):
+        ops.siren_loss_grad(desc, flat, torch.zeros_like(flat), x, t.reshape(-1), None, 0, torch.zeros(1, device="cuda"), None, 1)
+
+
 def _fit_worker(rank, world, seed_per_rank):
     x, t, w = _problem()
     n = x.shape[0]
