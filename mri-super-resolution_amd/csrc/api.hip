@@ -926,7 +926,7 @@ static int side_stream(SideStream** out) {
     *out = &s;
     return 0;
 }
-tune_int g_hp_side_stream{1};   // measured: -2 % per step at 4 k - 70 k rows, nothing at 524 k, identical bits (tools/side_stream_ab.py)
+tune_int g_hp_side_stream{1};   // measured: -2 % per step at 4 k - 70 k rows, nothing from 139 k up, identical bits (tools/side_stream_ab.py)
 
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
 // dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
@@ -994,7 +994,9 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         fin.nparts = blocks;
     }
     SideStream* side = nullptr;
-    if (g_hp_side_stream && L.n_sine > 1) {
+    // (only where it pays: at >= 131,072 rows each GEMM fills the chip for hundreds of microseconds and two of them side by
+    //  side gain nothing -- 8.79 against 8.79 ms per step at 524,288 rows -- while their per-kernel timings stop meaning anything)
+    if (g_hp_side_stream && L.n_sine > 1 && n < 131072) {
         if (int rc = side_stream(&side)) return rc;
     }
     for (int l = L.n_sine - 1; l >= 0; --l) {
