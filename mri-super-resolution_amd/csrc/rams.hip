@@ -566,6 +566,7 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
     else r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
     p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
     p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
+    p.mD3 = r3_magic(D3); p.mHP2 = r3_magic(p.PO2 + 2); p.mO3 = r3_magic(p.O3); p.mPO2 = r3_magic(p.PO2);
     const int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
     ProfScope ps(KC_OTHER, st);
     if (two_pass) {
