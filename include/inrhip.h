@@ -381,7 +381,8 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * fit (1 = persistent multi-step kernel, default; 0 = two launches per step); key 13 = its rows per block (0 choose,
  * 32, 64); key 14 = RAMS 32->32 convolutions (2 = split-fp16 MFMA, activations staged in LDS, default; 1 = split-fp16,
  * activations from global memory; 0 = f32-input MFMA; +4 forces the LDS-staged kernels); key 15 = which LDS-staged kernel
- * (8 = 8 waves x 1 tile, default; 4 = 4 waves x 2 tiles; 16 = two-pass 8 waves x 2 tiles); key 16 = last sine layer of a
+ * (42 = two blocks of 4 waves x 2 tiles per CU, one staged image each, default; 8 = 8 waves x 1 tile, two images; 4 = 4 waves
+ * x 2 tiles, two images; 16 = two-pass 8 waves x 2 tiles); key 16 = last sine layer of a
  * fit step stashes z only (1 default, 0 = act + omega cos); key 17 = poll limit of the small-network kernel's grid barrier (0 = built-in 2^22;
  * tests force the abandon path with 1); key 18 = 64-row tiles for GEMM launches with too few 128-row tiles to fill the chip
  * (1 default); key 19 = cross-layer fused forward for inr_siren_forward / inr_siren_reconstruct (0 default = one launch per layer; 1 =

@@ -1489,7 +1489,7 @@ const DebugKey* debug_table(int* count) {
         {3, &g_h3, 1, 0, 2},              {5, &g_h3_serpentine, 1, 0, 1},   {6, &g_h3_wide, 1, 0, 1},
         {7, &g_hp, 1, 0, 1},              {8, &g_stamp_class, -1, -1, 3},   {9, &g_stamp_nth, 0, 0, 1 << 30},
         {10, &g_hp_persistent, 2, 0, 2},  {11, &g_hp_stagger, 0, 0, 1 << 20}, {12, &g_small_multi, 1, 0, 1},
-        {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 8, 4, 16},
+        {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 42, 4, 42},
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
         {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},
     };
@@ -1501,7 +1501,7 @@ void debug_apply(const DebugKey& k, int value) {
         g_rams_h3 = value & 3;
         g_rams_force_lds = (value >> 2) & 1;
     } else if (k.key == 15) {
-        value = (value == 8 || value == 16) ? value : 4;
+        value = (value == 8 || value == 16 || value == 42) ? value : 4;
     } else if (k.key == 2) {
         set_hybrid_variant(value);
     }

@@ -506,8 +506,9 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 }
 
 int rams_waves_per_b(int B, int ovox);
-tune_int g_rams_lds_waves{8};   // LDS-staged kernel: 8 waves x 1 tile per block (default: 33.2 ms per 25 stacks) or 4 waves x 2 tiles
-                            // sharing the weight fragments (34.6 ms: one wave per SIMD hides less latency than it saves bytes)
+tune_int g_rams_lds_waves{42};  // LDS-staged kernel: 42 = two blocks of 4 waves x 2 tiles per CU, one staged image each (default: 26.6 ms
+                            // per 25 stacks); 8 = 8 waves x 1 tile, two images (29.2 ms); 4 = 4 waves x 2 tiles, two images, one block
+                            // per CU (one wave per SIMD hides less latency than the shared weight fragments save); 16 = two-pass
 tune_int g_rams_force_lds{0};   // (kept for the debug key's bit 2; the LDS-staged kernel is the default at every batch size now)
 tune_int g_rams_h3{2};   // inference convolutions: 2 = split-fp16 MFMA, activations staged in LDS (default); 1 = split-fp16,
                      // activations from global; 0 = f32-input MFMA
@@ -552,6 +553,7 @@ static int rams_lds_blocks_per_b(int B, int npatch) {
     return blocks < npatch ? blocks : npatch;
 }
 
+extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_debug_set_ptr(0, device buffer of 16 x u64)
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
                          const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
                          int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st) {
@@ -566,10 +568,19 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
     else r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
     p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
     p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
+    p.stamps = g_stamps;
     p.mD3 = r3_magic(D3); p.mHP2 = r3_magic(p.PO2 + 2); p.mO3 = r3_magic(p.O3); p.mPO2 = r3_magic(p.PO2);
-    const int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
+    p.mNP2 = r3_magic(p.np2);
+    INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 30) && (long long)p.O1 * p.O2 * p.O3 * y_cstride * 4 < (1ll << 30),
+                INR_E_INVALID, "RAMS convolution: an image of %d x %d x %d x 32 floats exceeds the kernel's 1 GiB per image", D1, D2, D3);
+    int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
     ProfScope ps(KC_OTHER, st);
-    if (two_pass) {
+    if (g_rams_lds_waves == 42) {                        // two blocks of 4 waves x 2 tiles per CU, one staged image each
+        blocks = 512 / B < 1 ? 1 : 512 / B;
+        if (blocks > p.np1 * p.np2) blocks = p.np1 * p.np2;
+        if (nslab) *nslab = blocks * 4;
+        hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true>), dim3(blocks, B), dim3(256), 0, st, p);
+    } else if (two_pass) {
         if (nslab) *nslab = blocks * 8;
         hipLaunchKernelGGL(conv3d_c32_lds2_kernel, dim3(blocks, B), dim3(512), 0, st, p);
     } else if (g_rams_lds_waves == 8) {

@@ -34,9 +34,10 @@ def test_full_size_stack_matches_oracle():
     # every path of the 32 -> 32 convolutions (debug key 14): 6 = split-fp16 MFMA with the activations staged in LDS, forced
     # (the default for batches; batch 1 at this size would take the f32 kernel), 2 = the default rule, 1 = split-fp16 with
     # the activations from global memory, 0 = the exact f32-input MFMA
-    for split, flips in ((6, 2e-2), (22, 2e-2), (2, 2e-2), (1, 2e-2), (0, 1e-2)):     # 22: key 14 = 6 with the two-pass kernel
-        lib().inr_debug_set(14, 6 if split == 22 else split)
-        lib().inr_debug_set(15, 16 if split == 22 else DEFAULT_LDS_KERNEL)
+    # 22 / 48: key 14 = 6 with the two-pass kernel / the two-blocks-per-CU kernel (key 15 = 16 / 42)
+    for split, flips in ((6, 2e-2), (22, 2e-2), (48, 2e-2), (2, 2e-2), (1, 2e-2), (0, 1e-2)):
+        lib().inr_debug_set(14, 6 if split in (22, 48) else split)
+        lib().inr_debug_set(15, {22: 16, 48: 42}.get(split, DEFAULT_LDS_KERNEL))
         try:
             got = model(x).cpu().numpy()
             assert got.shape == (2, 384, 384, 1)
@@ -57,7 +58,7 @@ def test_full_size_stack_matches_oracle():
 @pytest.fixture
 def conv_mode(request):
     """debug keys 14 / 15 for the duration of a test: key 14 = 2 default rule, 6 LDS-staged split-fp16 kernels forced, 1 / 0 the
-    others; key 15 = which LDS-staged kernel (8: 8 waves x 1 tile, 4: 4 x 2, 16: two-pass 8 x 2)"""
+    others; key 15 = which LDS-staged kernel (8: 8 waves x 1 tile, 4: 4 x 2, 16: two-pass 8 x 2, 42: two blocks of 4 x 2 per CU)"""
     from mri_super_resolution_amd._lib import lib
     k14, k15 = request.param if isinstance(request.param, tuple) else (request.param, None)
     lib().inr_debug_set(14, k14)
@@ -68,10 +69,10 @@ def conv_mode(request):
     lib().inr_debug_set(15, DEFAULT_LDS_KERNEL)
 
 
-DEFAULT_LDS_KERNEL = 8
+DEFAULT_LDS_KERNEL = 42
 
 
-@pytest.mark.parametrize("conv_mode", [2, (6, 8), (6, 4), (6, 16), 1], indirect=True)
+@pytest.mark.parametrize("conv_mode", [2, (6, 8), (6, 4), (6, 16), (6, 42), 1], indirect=True)
 @pytest.mark.parametrize("B,H,W", [(1, 24, 20), (3, 16, 16), (2, 13, 31)])
 def test_forward_matches_oracle(B, H, W, conv_mode):
     params = R.init_rams_params(seed=1, perturb_g=True)
