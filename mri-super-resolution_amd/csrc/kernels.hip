@@ -337,8 +337,9 @@ __global__ void __launch_bounds__(256) colsum_kernel(float* __restrict__ slab, c
 
 // out[g][i] = sum_{s in group g} slab[s][i]  (fixed order; group g = slabs [g*per_group, (g+1)*per_group))
 // grid = (ceil(len/256), groups).  With groups == 1 this is the plain slab reduction.
+// (slab s starts at slab + s * pitch: pitch == len for a dense stack, larger for partials interleaved with other fields)
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ out, const float* __restrict__ slab,
-                                                           int nslabs, int64_t len, int per_group) {
+                                                           int nslabs, int64_t len, int per_group, int64_t pitch) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     const int s0 = blockIdx.y * per_group;
@@ -346,12 +347,12 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ o
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int s = s0;
     for (; s + 3 < s1; s += 4) {
-        a0 += slab[(int64_t)s * len + i];
-        a1 += slab[(int64_t)(s + 1) * len + i];
-        a2 += slab[(int64_t)(s + 2) * len + i];
-        a3 += slab[(int64_t)(s + 3) * len + i];
+        a0 += slab[(int64_t)s * pitch + i];
+        a1 += slab[(int64_t)(s + 1) * pitch + i];
+        a2 += slab[(int64_t)(s + 2) * pitch + i];
+        a3 += slab[(int64_t)(s + 3) * pitch + i];
     }
-    for (; s < s1; ++s) a0 += slab[(int64_t)s * len + i];
+    for (; s < s1; ++s) a0 += slab[(int64_t)s * pitch + i];
     out[(int64_t)blockIdx.y * len + i] = (a0 + a1) + (a2 + a3);
 }
 
@@ -593,20 +594,23 @@ constexpr int REDUCE_GROUP = 32;
 int64_t reduce_tmp_floats(int64_t nslabs, int64_t len) {
     return nslabs > 4 * REDUCE_GROUP ? (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP * len : 0;
 }
-int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st) {
+int launch_reduce_slabs_pitched(float* out, const float* slab, int nslabs, int64_t len, int64_t pitch, float* tmp, hipStream_t st) {
     ProfScope ps(KC_OTHER, st);
     const unsigned gx = blocks_for(len, 256, 1 << 30);
     if (reduce_tmp_floats(nslabs, len) == 0) {
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, slab, nslabs, len, nslabs);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, slab, nslabs, len, nslabs, pitch);
         INR_LAUNCH_CHECK();
         return 0;
     }
     const int groups = (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, groups), dim3(256), 0, st, tmp, slab, nslabs, len, REDUCE_GROUP);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, groups), dim3(256), 0, st, tmp, slab, nslabs, len, REDUCE_GROUP, pitch);
     INR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, tmp, groups, len, groups);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, tmp, groups, len, groups, len);
     INR_LAUNCH_CHECK();
     return 0;
+}
+int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st) {
+    return launch_reduce_slabs_pitched(out, slab, nslabs, len, len, tmp, st);
 }
 
 // fused head backward for out_features == 1 (see head_bwd_fused_kernel)

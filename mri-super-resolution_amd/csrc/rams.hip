@@ -603,6 +603,17 @@ __global__ void __launch_bounds__(512) rams_weight_split_all_kernel(const R3Spli
     rams_weight_split_body(jobs.j[blockIdx.x]);
 }
 
+// max|x| of a tensor into a slot (the training step's convolution inputs: activations and gradients written by kernels
+// that do not track it)
+__global__ void __launch_bounds__(256) r3_tensor_amax_kernel(unsigned* __restrict__ slot, const float* __restrict__ x, long long n4) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    r3_block_amax(m, slot);
+}
+
 // ---- building blocks of the training step (utils/training.py:193-209) -------------------------------
 // data gradient of a 'same' 3x3x3 convolution = the same convolution of dy with the kernel flipped along every axis
 // and its channel axes swapped:  wd[tap'][co][ci] = w[26 - tap'][ci][co]
@@ -707,6 +718,7 @@ constexpr int WGRAD_BLOCKS = 512;        // target number of blocks (two per CU)
 constexpr int WGRAD_BLOCKS_MAX = 1024;   // slabs the workspace is sized for (blocks_per_b * B never exceeds max(512, B))
 int64_t reduce_tmp_floats(int64_t nslabs, int64_t len);
 int launch_reduce_slabs(float* out, const float* slab, int nslabs, int64_t len, float* tmp, hipStream_t st);
+int launch_reduce_slabs_pitched(float* out, const float* slab, int nslabs, int64_t len, int64_t pitch, float* tmp, hipStream_t st);
 int64_t colsum_ws_floats(int64_t n, int C, int G);
 int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab, hipStream_t st);
 

@@ -206,9 +206,12 @@ def _train_case(B=2, side=20, seed=3):
     return x, hr, mask
 
 
-def test_train_gradients_match_autograd():
+@pytest.mark.parametrize("conv_mode", [2, 0], indirect=True)
+def test_train_gradients_match_autograd(conv_mode):
     """Trainer.train_step (utils/training.py:193-209): gradients of all 71 layers (v, g, b: 213 tensors) of a (2, 20, 20, 9)
-    batch against torch autograd on the float64 restatement (itself unpinned against TensorFlow -- see the oracle)."""
+    batch against torch autograd on the float64 restatement (itself unpinned against TensorFlow -- see the oracle).  Both
+    arithmetic paths of the 32 -> 32 convolutions' forward and data gradient: split-fp16 MFMA staged through LDS (debug key 14 = 2,
+    default) and the f32-input MFMA kernels (0); the weight gradient is f32-input MFMA in both."""
     params = R.init_rams_params(seed=5, perturb_g=True)
     model = rams.RAMS(3, 32, 3, 9, 8, 12, params=params)
     x, hr, mask = _train_case()
@@ -220,14 +223,16 @@ def test_train_gradients_match_autograd():
     got = trainer.named_gradients()
     assert set(got) == set(want) and len(got) == 213
     worst = max((O.rel_l2(got[k], want[k]), k) for k in want if np.linalg.norm(want[k]) > 0)
-    assert worst[0] < 1e-4, worst                                  # fp32 pipeline (exact-fp32 MFMA) vs float64 autograd
+    assert worst[0] < 1e-4, worst                                  # fp32-class pipeline vs float64 autograd
     total = O.rel_l2(np.concatenate([got[k].reshape(-1) for k in sorted(want)]),
                      np.concatenate([want[k].reshape(-1) for k in sorted(want)]))
     assert total < 1e-5, total
 
 
-def test_train_steps_follow_keras_adam():
-    """Ten train_steps on a small RAMS (N = 2): the loss trajectory against the float64 restatement + Keras-form Adam."""
+@pytest.mark.parametrize("conv_mode", [2, 0], indirect=True)
+def test_train_steps_follow_keras_adam(conv_mode):
+    """Ten train_steps on a small RAMS (N = 2): the loss trajectory against the float64 restatement + Keras-form Adam, on both
+    arithmetic paths of the forward / data-gradient convolutions (debug key 14: 2 = split-fp16, default; 0 = f32-input MFMA)."""
     params = R.init_rams_params(seed=6, perturb_g=True, N=2)
     model = rams.RAMS(3, 32, 3, 9, 8, 2, params={k: v.copy() for k, v in params.items()})
     x, hr, mask = _train_case(B=2, side=16, seed=8)
@@ -249,4 +254,6 @@ def test_train_steps_follow_keras_adam():
     synced = trainer.sync_model()
     assert O.rel_l2(synced.params["rfab1/conv2/v"], p["rfab1/conv2/v"]) < 5e-3   # (observed 1.5e-3 after 10 Adam steps)
     out = synced(x).cpu().numpy()                                  # the inference path picks the trained weights up
-    assert O.rel_l2(out, R.rams_forward({k: v.astype(np.float32) for k, v in p.items()}, x, N=2)) < 5e-3
+    # (the same round-off amplification, seen through every layer: 4e-3 after ten steps on the f32-input kernels, 7e-3 on the
+    # split-fp16 ones -- a different rounding, not a larger one: the gradients of both meet float64 to the same 1e-4 / 1e-5 above)
+    assert O.rel_l2(out, R.rams_forward({k: v.astype(np.float32) for k, v in p.items()}, x, N=2)) < (5e-3 if conv_mode == 0 else 1.5e-2)
