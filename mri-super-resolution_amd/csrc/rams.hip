@@ -637,63 +637,71 @@ struct Conv3dWgradParams {
 };
 
 // grid = (blocks_per_b, B): a block stays inside one batch element, so both operands are read through per-block buffer
-// resources with 32-bit offsets, and an out-of-range tap is an offset past the resource (reads 0) -- per tap and voxel
-// one add, one select, one load.  The f32 MFMA shares the VALU lanes: address arithmetic is what this loop must not do.
+// resources with 32-bit offsets, and an out-of-range tap is an offset past the resource (reads 0).  The f32 MFMA shares the
+// VALU lanes: address arithmetic is what this loop must not do (at ~106 VALU per voxel pair -- three 3-bit range masks, the
+// 27-bit tap mask assembled from them, the offsets -- the kernel ran at 36 % of its MFMA time).  Now:
+//   * rows (axis 1) need no check at all: a tap above / below the image is a negative / too large offset, the resource's range
+//     check returns 0;
+//   * the column / temporal validity of the nine (d2, d3) combinations and the in-plane offset depend on (o2, o3) only: one LDS
+//     table entry per in-plane position, built once per block: bits 0-8 the mask, bits 9.. the offset (o2 - pad) * D3 + (o3 - pad)
+//     biased by D3 + 1;
+//   * per voxel pair and tap: bit extract, compare, add, select.
+constexpr int WGRAD_TAB_MAX = 16384;     // in-plane positions O2 * O3 the table may hold (dynamic LDS, 4 bytes each)
 __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWgradParams p) {
+    extern __shared__ unsigned tab[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
     const int b = blockIdx.y;
-    const int ovox = p.O1 * p.O2 * p.O3;
+    const int plane = p.O2 * p.O3;
+    const int ovox = p.O1 * plane;
     const int v0 = blockIdx.x * p.vox_per_block, v1 = min(ovox, v0 + p.vox_per_block);
     const long long xb = (long long)p.D1 * p.D2 * p.D3 * RC, yb = (long long)ovox * RC;
     const __amdgpu_buffer_rsrc_t srdx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + b * xb), 0, (int)(xb * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t srdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + b * yb), 0, (int)(yb * 4), 0x00020000);
+    for (int i = threadIdx.x; i < plane; i += 512) {
+        const int o2 = i / p.O3, o3 = i - o2 * p.O3;
+        unsigned mk = 0;
+#pragma unroll
+        for (int e2 = 0; e2 < 3; ++e2)
+#pragma unroll
+            for (int e3 = 0; e3 < 3; ++e3)
+                if ((unsigned)(o2 + e2 - p.pad) < (unsigned)p.D2 && (unsigned)(o3 + e3 - p.pad) < (unsigned)p.D3) mk |= 1u << (3 * e2 + e3);
+        tab[i] = mk | ((unsigned)((o2 - p.pad) * p.D3 + (o3 - p.pad) + p.D3 + 1) << 9);
+    }
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    int delta[4], sh[4];   // wave-uniform: byte offset of the tap inside x, bit position of the tap in the 27-bit mask
+    int delta[4], sh[4];   // wave-uniform: byte offset of the tap inside x (less the table's bias), bit of its (d2, d3) in the mask
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int tap = wave + 8 * t;   // tap 27..31: idle slot of waves 3..7
-        delta[t] = (((tap / 9) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3) * RC * 4;
-        sh[t] = tap < 27 ? tap : 31;    // bit 31 of the mask is never set
+        delta[t] = ((((tap / 9) - p.pad) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3 - (p.D3 + 1)) * RC * 4;
+        sh[t] = tap < 27 ? tap % 9 : 31;    // bit 31 of an entry is never set (offsets stay below 2^22)
     }
-    // this lane's running output voxel: v0 + h, + 2 per MFMA k-step
+    __syncthreads();
+    // this lane's running output voxel: v0 + h, + 2 per MFMA k-step; idx = its in-plane position, row = byte offset of its x row
     int v = v0 + h;
-    int o3 = v % p.O3, o2 = (v / p.O3) % p.O2, o1 = v / (p.O3 * p.O2);
+    int idx = v % plane;
+    int row = (v / plane) * p.D2 * p.D3 * RC * 4 + l32 * 4;
+    const int row_step = p.D2 * p.D3 * RC * 4;
     for (int vb = v0; vb < v1; vb += 8) {
         float dyv[4], xv[4][4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool ok = v < v1;
-            const int base = ((((o1 - p.pad) * p.D2 + (o2 - p.pad)) * p.D3 + (o3 - p.pad)) * RC + l32) * 4;
-            unsigned m1 = 0, m2 = 0, m3 = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                m1 |= ((unsigned)(o1 + d - p.pad) < (unsigned)p.D1) ? (1u << d) : 0u;
-                m2 |= ((unsigned)(o2 + d - p.pad) < (unsigned)p.D2) ? (1u << d) : 0u;
-                m3 |= ((unsigned)(o3 + d - p.pad) < (unsigned)p.D3) ? (1u << d) : 0u;
-            }
-            unsigned mk = 0;
-#pragma unroll
-            for (int e1 = 0; e1 < 3; ++e1)
-#pragma unroll
-                for (int e2 = 0; e2 < 3; ++e2) mk |= (((m1 >> e1) & (m2 >> e2) & 1u) ? m3 : 0u) << (9 * e1 + 3 * e2);
-            if (!ok) mk = 0;
+            const unsigned e = ok ? tab[idx] : 0u;
+            const int base = row + (int)(e >> 9) * (RC * 4);
             dyv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdy, ok ? (v * RC + l32) * 4 : 0x7F000000, 0, 0));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 xv[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                         srdx, ((mk >> sh[t]) & 1u) ? base + delta[t] : 0x7F000000, 0, 0));
+                                                         srdx, ((e >> sh[t]) & 1u) ? base + delta[t] : 0x7F000000, 0, 0));
             v += 2;
-            o3 += 2;
-            while (o3 >= p.O3) {
-                o3 -= p.O3;
-                if (++o2 >= p.O2) {
-                    o2 = 0;
-                    ++o1;
-                }
+            idx += 2;
+            while (idx >= plane) {
+                idx -= plane;
+                row += row_step;
             }
         }
 #pragma unroll
@@ -762,9 +770,11 @@ int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int
     const int nslabs = blocks_per_b * B;
     INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 31) && nslabs <= WGRAD_BLOCKS_MAX, INR_E_INVALID,
                 "conv3d wgrad: one batch element must stay below 2 GiB and B below %d", WGRAD_BLOCKS_MAX);
+    INR_REQUIRE(p.O2 * p.O3 >= 1 && p.O2 * p.O3 <= WGRAD_TAB_MAX, INR_E_INVALID,
+                "conv3d wgrad: %d x %d in-plane output positions exceed the kernel's table of %d", p.O2, p.O3, WGRAD_TAB_MAX);
     {
         ProfScope ps(KC_OTHER, st);
-        hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(blocks_per_b, B), dim3(512), 0, st, p);
+        hipLaunchKernelGGL(conv3d_c32_wgrad_kernel, dim3(blocks_per_b, B), dim3(512), (size_t)p.O2 * p.O3 * sizeof(unsigned), st, p);
         INR_LAUNCH_CHECK();
     }
     if (int rc = launch_reduce_slabs(gw, ws, nslabs, CONV_W_FLOATS, ws + (size_t)nslabs * CONV_W_FLOATS, st)) return rc;
