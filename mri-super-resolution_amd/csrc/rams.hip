@@ -643,9 +643,9 @@ struct Conv3dWgradParams {
 //   * rows (axis 1) need no check at all: a tap above / below the image is a negative / too large offset, the resource's range
 //     check returns 0;
 //   * the column / temporal validity of the nine (d2, d3) combinations and the in-plane offset depend on (o2, o3) only: one LDS
-//     table entry per in-plane position, built once per block: bits 0-8 the mask, bits 9.. the offset (o2 - pad) * D3 + (o3 - pad)
-//     biased by D3 + 1;
-//   * per voxel pair and tap: bit extract, compare, add, select.
+//     table entry per in-plane position, built once per block: bits 0-8 the mask (1 = outside), bits 9.. the offset
+//     (o2 - pad) * D3 + (o3 - pad) biased by D3 + 1;
+//   * per voxel pair and tap: a signed one-bit extract (0 or all ones), an add, an or -- all ones is past every resource.
 constexpr int WGRAD_TAB_MAX = 16384;     // in-plane positions O2 * O3 the table may hold (dynamic LDS, 4 bytes each)
 __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWgradParams p) {
     extern __shared__ unsigned tab[];
@@ -664,8 +664,8 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
         for (int e2 = 0; e2 < 3; ++e2)
 #pragma unroll
             for (int e3 = 0; e3 < 3; ++e3)
-                if ((unsigned)(o2 + e2 - p.pad) < (unsigned)p.D2 && (unsigned)(o3 + e3 - p.pad) < (unsigned)p.D3) mk |= 1u << (3 * e2 + e3);
-        tab[i] = mk | ((unsigned)((o2 - p.pad) * p.D3 + (o3 - p.pad) + p.D3 + 1) << 9);
+                if (!((unsigned)(o2 + e2 - p.pad) < (unsigned)p.D2 && (unsigned)(o3 + e3 - p.pad) < (unsigned)p.D3)) mk |= 1u << (3 * e2 + e3);
+        tab[i] = 0x80000000u | mk | ((unsigned)((o2 - p.pad) * p.D3 + (o3 - p.pad) + p.D3 + 1) << 9);   // bit 31: "outside" for idle slots
     }
     f32x16 acc[4];
 #pragma unroll
@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
     for (int t = 0; t < 4; ++t) {
         const int tap = wave + 8 * t;   // tap 27..31: idle slot of waves 3..7
         delta[t] = ((((tap / 9) - p.pad) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3 - (p.D3 + 1)) * RC * 4;
-        sh[t] = tap < 27 ? tap % 9 : 31;    // bit 31 of an entry is never set (offsets stay below 2^22)
+        sh[t] = tap < 27 ? tap % 9 : 31;
     }
     __syncthreads();
     // this lane's running output voxel: v0 + h, + 2 per MFMA k-step; idx = its in-plane position, row = byte offset of its x row
@@ -690,13 +690,13 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool ok = v < v1;
-            const unsigned e = ok ? tab[idx] : 0u;
-            const int base = row + (int)(e >> 9) * (RC * 4);
+            const unsigned e = ok ? tab[idx] : 0x800001ffu;
+            const int base = row + (int)((e >> 9) & 0x3fffffu) * (RC * 4);
             dyv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdy, ok ? (v * RC + l32) * 4 : 0x7F000000, 0, 0));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 xv[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                         srdx, ((e >> sh[t]) & 1u) ? base + delta[t] : 0x7F000000, 0, 0));
+                                                         srdx, (base + delta[t]) | __builtin_amdgcn_sbfe((int)e, sh[t], 1), 0, 0));
             v += 2;
             idx += 2;
             while (idx >= plane) {
