@@ -679,6 +679,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
         delta[t] = ((((tap / 9) - p.pad) * p.D2 + (tap / 3) % 3) * p.D3 + tap % 3 - (p.D3 + 1)) * RC * 4;
         sh[t] = tap < 27 ? tap % 9 : 31;
     }
+    const bool fourth = wave + 24 < 27;
     __syncthreads();
     // this lane's running output voxel: v0 + h, + 2 per MFMA k-step; idx = its in-plane position, row = byte offset of its x row
     int v = v0 + h;
@@ -686,7 +687,7 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
     int row = (v / plane) * p.D2 * p.D3 * RC * 4 + l32 * 4;
     const int row_step = p.D2 * p.D3 * RC * 4;
     for (int vb = v0; vb < v1; vb += 8) {
-        float dyv[4], xv[4][4];
+        float dyv[4], xv[4][4] = {};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bool ok = v < v1;
@@ -695,8 +696,9 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
             dyv[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srdy, ok ? (v * RC + l32) * 4 : 0x7F000000, 0, 0));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                xv[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                         srdx, (base + delta[t]) | __builtin_amdgcn_sbfe((int)e, sh[t], 1), 0, 0));
+                if (t < 3 || fourth)      // (wave-uniform: waves 3..7 have no fourth tap -- no load, no MFMA for it)
+                    xv[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             srdx, (base + delta[t]) | __builtin_amdgcn_sbfe((int)e, sh[t], 1), 0, 0));
             v += 2;
             idx += 2;
             while (idx >= plane) {
@@ -707,7 +709,11 @@ __global__ void __launch_bounds__(512, 2) conv3d_c32_wgrad_kernel(const Conv3dWg
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][s], dyv[s], acc[t], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[t][s], dyv[s], acc[t], 0, 0, 0);
+        if (fourth) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[3][s], dyv[s], acc[3], 0, 0, 0);
+        }
     }
     // C/D map: col = lane & 31 (co), row = (r & 3) + 8 (r >> 2) + 4 h (ci)
     const long long blk = (long long)b * gridDim.x + blockIdx.x;
