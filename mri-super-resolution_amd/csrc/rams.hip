@@ -603,6 +603,8 @@ __global__ void __launch_bounds__(512) rams_weight_split_all_kernel(const R3Spli
     rams_weight_split_body(jobs.j[blockIdx.x]);
 }
 
+#include "rams_wgrad_h3.inc"
+
 // max|x| of a tensor into a slot (the training step's convolution inputs: activations and gradients written by kernels
 // that do not track it)
 __global__ void __launch_bounds__(256) r3_tensor_amax_kernel(unsigned* __restrict__ slot, const float* __restrict__ x, long long n4) {
@@ -789,6 +791,34 @@ int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int
 }
 
 // number of waves per batch element for the conv kernel: fill the chip once, never more waves than tiles
+// the same gradient on the split-fp16 kernel; xs / ds: slots holding max|x| and max|dy| (R3_SLOT words each)
+int rams_conv3d_wgrad_h3(float* gw, float* gb, const float* x, const float* dy, const unsigned* xs, const unsigned* ds, int B, int D1,
+                         int D2, int D3, int pad, float* ws, hipStream_t st) {
+    Conv3dWgradH3Params p{};
+    p.x = x; p.dy = dy; p.slab = ws; p.x_amax = xs; p.dy_amax = ds;
+    p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3; p.pad = pad;
+    p.O1 = D1 + 2 * pad - 2; p.O2 = D2 + 2 * pad - 2; p.O3 = D3 + 2 * pad - 2;
+    r3l_choose_patch(D3, p.O3, &p.PO1, &p.PO2);
+    p.np1 = (p.O1 + p.PO1 - 1) / p.PO1;
+    p.np2 = (p.O2 + p.PO2 - 1) / p.PO2;
+    p.mD3 = r3_magic(D3); p.mHP2 = r3_magic(p.PO2 + 2); p.mO3 = r3_magic(p.O3); p.mPO2 = r3_magic(p.PO2); p.mNP2 = r3_magic(p.np2);
+    const int ovox = p.O1 * p.O2 * p.O3;
+    int blocks_per_b = 256 / B < 1 ? 1 : 256 / B;               // one block (107 KB of LDS) per CU
+    if (blocks_per_b > p.np1 * p.np2) blocks_per_b = p.np1 * p.np2;
+    const int nslabs = blocks_per_b * B;
+    INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 30) && nslabs <= WGRAD_BLOCKS_MAX && D3 * 9 <= R3L_MAX_HVOX, INR_E_INVALID,
+                "conv3d wgrad (split-fp16): one batch element must stay below 1 GiB, B below %d, depth below %d", WGRAD_BLOCKS_MAX,
+                R3L_MAX_HVOX / 9 + 1);
+    {
+        ProfScope ps(KC_OTHER, st);
+        hipLaunchKernelGGL(conv3d_c32_wgrad_h3_kernel, dim3(blocks_per_b, B), dim3(512), 0, st, p);
+        INR_LAUNCH_CHECK();
+    }
+    if (int rc = launch_reduce_slabs(gw, ws, nslabs, CONV_W_FLOATS, ws + (size_t)nslabs * CONV_W_FLOATS, st)) return rc;
+    if (gb) return launch_colsum(gb, dy, nullptr, (long long)B * ovox, RC, 1, ws, st);
+    return 0;
+}
+
 int rams_waves_per_b(int B, int ovox) {
     const int tiles = (ovox + 31) / 32;
     int blocks = 256 / B;                           // one 8-wave block per CU (108 KB of LDS each): never more than 256

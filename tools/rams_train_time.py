@@ -21,4 +21,4 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 # forward 265 GFLOP per 128x128 stack scales with the patch area; a step is ~3 forward-equivalents (forward, data grad, weight grad)
 fwd = 265e9 * (P * P) / (128 * 128) * B
-print(f"RAMS train_step batch {B} of {P}x{P}x9: {dt * 1e3:.1f} ms per step, ~{3 * fwd / dt / 1e12:.0f} TFLOP/s (forward / data gradient: split-fp16 MFMA, weight gradient: f32-input MFMA)")
+print(f"RAMS train_step batch {B} of {P}x{P}x9: {dt * 1e3:.1f} ms per step, ~{3 * fwd / dt / 1e12:.0f} TFLOP/s (32 -> 32 convolutions: forward, data and weight gradient on split-fp16 MFMA)")
