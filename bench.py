@@ -248,8 +248,9 @@ def eleven_patients_leg(steps):
 def rams_leg(reps=3):
     """Config 3 (multi-image CNN): RAMS(3,32,3,9,8,12) forward on synthetic (B,128,128,9) uint16-range stacks: B = 25 = the
     25 random 9-acquisition subsets of one case (multi-image-super-resolution/master.py:43-52) as one batched call, and
-    B = 1, the reference's own call shape.  The 32 -> 32 convolutions run on the fp16 matrix cores with hi/lo-split operands
-    (activations staged in LDS) for batches, on the f32-input MFMA at batch 1."""
+    B = 1, the reference's own call shape; and one `train_step` (utils/training.py:193-209) at the reference's training shape,
+    batch 32 of 32x32x9 patches.  The 32 -> 32 convolutions -- forward, data gradient and weight gradient -- run on the fp16 matrix
+    cores with hi/lo-split operands staged in LDS."""
     from mri_super_resolution_amd import rams
     model = rams.RAMS(seed=0)
     out = {"config": "RAMS(3,32,3,9,8,12) predict_tensor, (B,128,128,9) -> (384,384), random weights", "flop_per_stack": 265.0e9,
@@ -265,6 +266,22 @@ def rams_leg(reps=3):
         dt = (time.perf_counter() - t0) / reps
         out[f"batch{batch}"] = {"ms_per_stack": dt / batch * 1e3, "stacks_per_s": batch / dt,
                                 "output_voxels_per_s": batch * 384 * 384 / dt, "tflops": 265.0e9 * batch / dt / 1e12}
+    # training step: ~3 forward-equivalents (forward, data gradient, weight gradient) of 32 patches of 32 x 32 x 9
+    B, P = 32, 32
+    rng = np.random.default_rng(1)
+    tr = rams.RamsTrainer(model)
+    lr = (rng.random((B, P, P, 9)) * 20000).astype(np.float32)
+    hr = (rng.random((B, 3 * P, 3 * P, 1)) * 20000).astype(np.float32)
+    mask = np.ones((B, 3 * P, 3 * P, 1), np.float32)
+    tr.train_step(lr, hr, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tr.train_step(lr, hr, mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["train_step"] = {"batch": B, "patch": P, "ms_per_step": dt * 1e3,
+                         "tflops": 3 * 265.0e9 * (P * P) / (128 * 128) * B / dt / 1e12}
     return out
 
 
