@@ -320,7 +320,9 @@ int inr_rams_shift_loss(double* out, const float* y_true, const float* y_pred, c
  *   forward: y = conv(x, w) + bias (+ReLU)                                   -- the inference kernel, on its own
  *   dgrad  : dx = d loss / d x of a 'same' convolution, given dy             -- the same kernel on the flipped, transposed w
  *   wgrad  : gw[27][32][32] = d loss / d w, gb[32] = d loss / d bias (nullable) -- MFMA contraction over the voxels,
- *            fixed-order slab reduction (bitwise reproducible) */
+ *            fixed-order slab reduction (bitwise reproducible); arithmetic as in the training step: split-fp16 MFMA on
+ *            operands staged in LDS (default), f32-input MFMA under inr_debug_set(14, 0); x and dy 16-byte aligned
+ * (forward and dgrad here are the f32-input kernels; inside inr_rams_forward / inr_rams_train_* they follow key 14 too) */
 int inr_rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
                             int relu, void* stream);
 size_t inr_rams_conv3d_dgrad_workspace_bytes(void);

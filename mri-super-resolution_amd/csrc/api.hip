@@ -161,6 +161,8 @@ int rams_conv3d_forward(float* y, const float* x, const float* w, const float* b
 int rams_conv3d_dgrad_same(float* dx, const float* dy, const float* w, int B, int D1, int D2, int D3, float* ws, hipStream_t st);
 int rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
                       hipStream_t st);
+int rams_conv3d_wgrad_auto(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
+                      hipStream_t st);
 int launch_shift_loss_grad(double* loss, float* grad, const float* y_true, const float* y_pred, const float* mask,
                            const float* upstream, int nimg, int size, int border, double* ws, hipStream_t st);
 int launch_shift_loss(double* out, const float* y_true, const float* y_pred, const float* mask, int nimg, int size,
@@ -1300,7 +1302,8 @@ int inr_rams_conv3d_wgrad(float* gw, float* gb, const float* x, const float* dy,
     if (int rc = conv3d_dims_ok(B, D1, D2, D3, pad)) return rc;
     INR_REQUIRE(workspace && workspace_bytes >= inr_rams_conv3d_wgrad_workspace_bytes(B, D1, D2, D3, pad), INR_E_WORKSPACE,
                 "inr_rams_conv3d_wgrad: workspace too small");
-    return rams_conv3d_wgrad(gw, gb, x, dy, B, D1, D2, D3, pad, (float*)workspace, (hipStream_t)stream);
+    INR_REQUIRE(aligned16(x) && aligned16(dy), INR_E_ALIGN, "inr_rams_conv3d_wgrad: x / dy must be 16-byte aligned");
+    return rams_conv3d_wgrad_auto(gw, gb, x, dy, B, D1, D2, D3, pad, (float*)workspace, (hipStream_t)stream);
 }
 
 size_t inr_rams_shift_loss_grad_workspace_bytes(int n_images, int border) {

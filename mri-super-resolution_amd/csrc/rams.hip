@@ -741,7 +741,7 @@ int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, 
 size_t rams_conv3d_wgrad_ws_floats(long long nvox) {
     const size_t a = (size_t)WGRAD_BLOCKS_MAX * CONV_W_FLOATS + (size_t)reduce_tmp_floats(WGRAD_BLOCKS_MAX, CONV_W_FLOATS);
     const size_t b = (size_t)colsum_ws_floats(nvox, RC, 1);
-    return (a > b ? a : b) + 64;
+    return (a > b ? a : b) + 64 + 2 * R3_SLOT + 64;      // (+ two max|.| slots for the stand-alone split-fp16 call)
 }
 
 int rams_conv3d_forward(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, int pad,
@@ -817,6 +817,26 @@ int rams_conv3d_wgrad_h3(float* gw, float* gb, const float* x, const float* dy, 
     if (int rc = launch_reduce_slabs(gw, ws, nslabs, CONV_W_FLOATS, ws + (size_t)nslabs * CONV_W_FLOATS, st)) return rc;
     if (gb) return launch_colsum(gb, dy, nullptr, (long long)B * ovox, RC, 1, ws, st);
     return 0;
+}
+
+// stand-alone weight gradient (the C-ABI building block): the arithmetic debug key 14 selects, like the training step
+int rams_conv3d_wgrad_auto(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
+                           hipStream_t st) {
+    if (g_rams_h3 != 2 || D3 * 9 > R3L_MAX_HVOX) return rams_conv3d_wgrad(gw, gb, x, dy, B, D1, D2, D3, pad, ws, st);
+    const long long nvox = (long long)B * (D1 + 2 * pad - 2) * (D2 + 2 * pad - 2) * (D3 + 2 * pad - 2);
+    float* tail = ws + (rams_conv3d_wgrad_ws_floats(nvox > 0 ? nvox : 1) - (2 * R3_SLOT + 64));
+    unsigned* slots = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(tail) + 63) & ~(uintptr_t)63);
+    INR_HIP(hipMemsetAsync(slots, 0, 2 * R3_SLOT * sizeof(unsigned), st));
+    auto amax = [&](unsigned* slot, const float* t, long long n) {
+        long long g = (n / 4 + 255) / 256;
+        if (g > 2048) g = 2048;
+        if (g < 1) g = 1;
+        hipLaunchKernelGGL(r3_tensor_amax_kernel, dim3((unsigned)g), dim3(256), 0, st, slot, t, n / 4);
+    };
+    amax(slots, x, (long long)B * D1 * D2 * D3 * RC);
+    amax(slots + R3_SLOT, dy, nvox * RC);
+    INR_LAUNCH_CHECK();
+    return rams_conv3d_wgrad_h3(gw, gb, x, dy, slots, slots + R3_SLOT, B, D1, D2, D3, pad, ws, st);
 }
 
 int rams_waves_per_b(int B, int ovox) {

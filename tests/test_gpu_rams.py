@@ -168,10 +168,12 @@ def test_shift_loss_gradient_matches_autograd():
     assert torch.equal(loss1, loss) and np.allclose(grad1[1].cpu().numpy() * 0.5, g[1], rtol=1e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("shape,pad", [((2, 10, 9, 5), 1), ((1, 7, 8, 9), 0), ((3, 12, 6, 3), 1)])
-def test_conv3d_forward_and_gradients_vs_torch(shape, pad):
+@pytest.mark.parametrize("conv_mode", [2, 0], indirect=True)
+@pytest.mark.parametrize("shape,pad", [((2, 10, 9, 5), 1), ((1, 7, 8, 9), 0), ((3, 12, 6, 3), 1), ((2, 21, 33, 9), 1)])
+def test_conv3d_forward_and_gradients_vs_torch(shape, pad, conv_mode):
     """The 3x3x3 convolution 32 -> 32 on its own, its data gradient ('same') and its weight / bias gradients against
-    torch's conv3d + autograd in float64."""
+    torch's conv3d + autograd in float64.  The weight gradient follows debug key 14 like the training step: 2 = split-fp16 MFMA
+    (conv3d_c32_wgrad_h3_kernel: ragged patches, depths 3 / 5 / 9, valid and 'same'), 0 = f32-input MFMA."""
     import torch.nn.functional as F
     B, D1, D2, D3 = shape
     g = torch.Generator().manual_seed(sum(shape) + pad)
