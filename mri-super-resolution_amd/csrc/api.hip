@@ -104,6 +104,8 @@ int64_t hp_head_blocks(int64_t n);
 int hp_param_grad_splits(int64_t n, int in_f, int out_f);
 int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
                         HpScale sa, HpScale sb, hipStream_t stream);
+int hp_param_grad_multi_max();
+int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStream_t stream);
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
                     float clamp_min, hipStream_t stream);
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
@@ -903,32 +905,14 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
 }
 
 
-// ---- a side stream for the parameter-gradient GEMMs (inr_debug_set(20, 0) puts them back in line) ---------------------------
-// dW_l = dz_l^T act_l and dz_{l-1} = (dz_l W_l) * dact_{l-1} read the same dz_l and write different buffers (the deferred slab
-// regions made that so): they can run side by side -- the ramp-up of one under the drain of the other.  One non-blocking stream
-// and two events per device, created on first use (the only objects the library ever creates; a fork / join of events is
-// graph-capturable).
-struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
-static int side_stream(SideStream** out) {
-    static std::mutex mu;
-    static SideStream per_device[16];
-    int dev = 0;
-    INR_HIP(hipGetDevice(&dev));
-    INR_REQUIRE(dev >= 0 && dev < 16, INR_E_INVALID, "side stream: device index %d", dev);
-    std::lock_guard<std::mutex> lk(mu);
-    SideStream& s = per_device[dev];
-    if (!s.stream) {
-        INR_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        INR_HIP(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-        INR_HIP(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
-    }
-    *out = &s;
-    return 0;
-}
-tune_int g_hp_side_stream{1};   // measured: -2 % per step at 4 k - 70 k rows, nothing from 139 k up, identical bits (tools/side_stream_ab.py)
+// ---- the parameter-gradient GEMMs of a small step: one launch for all layers (inr_debug_set(20, 0): one launch per layer) ------
+// dW_l = dz_l^T act_l depends on the stashed activations and on dz_l only: all of them can wait until the input-gradient chain
+// has produced every dz, and then run as ONE launch (gemm_hp_rc_multi_kernel).  At a few thousand rows a single one fills at
+// most half the chip for 13 us: one launch per layer put four launch boundaries on the critical path, a second stream (the first
+// form of this switch) traded them for event hand-shakes of 7-13 us each (rocprofv3 timeline of a 4,096-row step: 223 us, of
+// which 28 in such gaps).  Measured, ms per step, one launch per layer / merged (tools/side_stream_ab.py): 2,048 rows 0.180 /
+// 0.144, 4,096: 0.223 / 0.200, 8,192: 0.322 / 0.320, 12,288: 0.413 / 0.422, 32,768: 0.671 / 0.679 -- merged up to 8,192 rows.
+tune_int g_hp_side_stream{1};   // (the name of the first form; key 20) identical bits either way
 
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
 // dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
@@ -995,24 +979,20 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         fin.part_loss = part_loss;
         fin.nparts = blocks;
     }
-    SideStream* side = nullptr;
-    // (only where it pays: at >= 131,072 rows each GEMM fills the chip for hundreds of microseconds and two of them side by
-    //  side gain nothing -- 8.79 against 8.79 ms per step at 524,288 rows -- while their per-kernel timings stop meaning anything)
-    if (g_hp_side_stream && L.n_sine > 1 && n < 131072) {
-        if (int rc = side_stream(&side)) return rc;
-    }
+    // (only where it pays: see above)
+    const bool merge = g_hp_side_stream && L.n_sine > 1 && n <= 8192 && L.n_sine <= hp_param_grad_multi_max();
+    HpParamGradJob jobs[16];
+    int njobs = 0;
     for (int l = L.n_sine - 1; l >= 0; --l) {
         const char* dz = reinterpret_cast<const char*>(dact[l]);
         const int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);
-        hipStream_t st_w = st;
-        if (side) {   // dz_l is complete on `st`: the side stream may start dW_l while `st` goes on with dX_l
-            INR_HIP(hipEventRecord(side->fork, st));
-            INR_HIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-            st_w = side->stream;
-        }
-        if (int rc = hp_param_grad_slabs(const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), n, L.fan_in[l],
-                                         L.fan_out[l], dz_scale(l), net.act_scale(l), st_w))
+        if (merge) {
+            jobs[njobs++] = HpParamGradJob{const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), L.fan_in[l], L.fan_out[l],
+                                           dz_scale(l), net.act_scale(l)};
+        } else if (int rc = hp_param_grad_slabs(const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), n, L.fan_in[l],
+                                                L.fan_out[l], dz_scale(l), net.act_scale(l), st)) {
             return rc;
+        }
         fin.seg[2 * l].nslabs = splits;
         if (l > 0) {
             int rows = 0;
@@ -1023,9 +1003,8 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
             fin.seg[2 * (l - 1) + 1].nslabs = rows;
         }
     }
-    if (side) {   // join: the caller's finalize launch (and the next step's forward) must see every dW slab
-        INR_HIP(hipEventRecord(side->join, side->stream));
-        INR_HIP(hipStreamWaitEvent(st, side->join, 0));
+    if (merge) {
+        if (int rc = hp_param_grad_multi(jobs, njobs, n, st)) return rc;
     }
     return 0;
 }

@@ -65,6 +65,16 @@ struct HpScale {
     float mul = 0.f;                  // 0 = no scale at all (tensor in [-1, 1]: sine outputs)
 };
 
+// one parameter-gradient GEMM of a step (hp_param_grad_multi: all of them in one launch)
+struct HpParamGradJob {
+    float* slabs;
+    int splits;
+    const char* dz_hl;
+    const char* x_hl;
+    int in_f, out_f;
+    HpScale sa, sb;
+};
+
 // Process-global diagnostic switches behind inr_debug_set (atomics: a read races with nothing, but a switch flipped while
 // another thread is enqueueing changes that thread's kernel selection -- diagnostic use only, see include/inrhip.h).
 typedef std::atomic<int> tune_int;

@@ -1446,9 +1446,9 @@ int hp_param_grad_splits(int64_t n, int in_f, int out_f) {
 }
 
 // slabs[splits][out_f][in_f] = partial dz^T x over row ranges (dz, x: HL32)
-int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
-                        HpScale sa, HpScale sb, hipStream_t stream) {
-    HpParams p{};
+static int hp_param_grad_params(HpParams& p, float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f,
+                                int out_f, HpScale sa, HpScale sb) {
+    p = HpParams{};
     p.A = dz_hl; p.B = x_hl;
     p.M = out_f; p.N = in_f; p.K = (int)n;
     p.pitchA = (long long)out_f * 4; p.pitchB = (long long)in_f * 4;
@@ -1461,13 +1461,41 @@ int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char*
     p.slab_stride = (long long)out_f * in_f;
     INR_REQUIRE((long long)p.k_per_split * (p.pitchA > p.pitchB ? p.pitchA : p.pitchB) < (1ll << 31), INR_E_INVALID,
                 "hp_param_grad_slabs: row range per split too large for 32-bit offsets");
-    if (int rc = hp_check_grid(p)) return rc;
+    return hp_check_grid(p);
+}
+int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char* x_hl, int64_t n, int in_f, int out_f,
+                        HpScale sa, HpScale sb, hipStream_t stream) {
+    HpParams p;
+    if (int rc = hp_param_grad_params(p, slabs, splits, dz_hl, x_hl, n, in_f, out_f, sa, sb)) return rc;
     const dim3 grid((unsigned)((long long)p.tiles_m * p.tiles_n * p.splits)), block(HP_NTH);
     p.stamps = hp_stamp_target(KC_GEMM_DW);
     ProfScope ps(KC_GEMM_DW, stream);
     hipLaunchKernelGGL((gemm_hp_kernel<HP_RC, HPE_SLAB>), grid, block, 0, stream, p);
     INR_LAUNCH_CHECK();
     count_launch(LF_HP_RC);
+    return 0;
+}
+
+// the same GEMMs, `jobs` of them (<= hp_param_grad_multi_max()) in one launch; every job counts as one launch of its family
+int hp_param_grad_multi_max() { return HP_MULTI_MAX; }
+int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStream_t stream) {
+    INR_REQUIRE(njobs >= 1 && njobs <= HP_MULTI_MAX, INR_E_INVALID, "hp_param_grad_multi: %d jobs (1 .. %d)", njobs, HP_MULTI_MAX);
+    HpMultiParams m{};
+    long long blocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (int rc = hp_param_grad_params(m.p[j], jobs[j].slabs, jobs[j].splits, jobs[j].dz_hl, jobs[j].x_hl, n, jobs[j].in_f,
+                                          jobs[j].out_f, jobs[j].sa, jobs[j].sb))
+            return rc;
+        m.first[j] = (int)blocks;
+        blocks += (long long)m.p[j].tiles_m * m.p[j].tiles_n * m.p[j].splits;
+    }
+    m.first[njobs] = (int)blocks;
+    m.jobs = njobs;
+    INR_REQUIRE(blocks < (1ll << 30), INR_E_INVALID, "hp_param_grad_multi: %lld blocks", blocks);
+    ProfScope ps(KC_GEMM_DW, stream);
+    hipLaunchKernelGGL(gemm_hp_rc_multi_kernel, dim3((unsigned)blocks), dim3(HP_NTH), 0, stream, m);
+    INR_LAUNCH_CHECK();
+    for (int j = 0; j < njobs; ++j) count_launch(LF_HP_RC);
     return 0;
 }
 

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of inr_debug_set(20, v): parameter-gradient GEMMs on a side stream (1) or in line (0); ms per fused step by row count."""
+"""A/B of inr_debug_set(20, v): the parameter-gradient GEMMs of a step in ONE launch behind the input-gradient chain (1; the first
+form of the switch put them on a second stream, hence the file name) or one launch per layer, in line (0); ms per fused step by
+row count (`python tools/side_stream_ab.py [rows ...]`)."""
 import os
 import sys
 import time
@@ -10,7 +12,8 @@ import torch  # noqa: E402
 import mri_super_resolution_amd as inr  # noqa: E402
 from mri_super_resolution_amd import ops  # noqa: E402
 
-for n in (4096, 16384, 69632, 139264, 524288):
+ROWS = tuple(int(a) for a in sys.argv[1:]) or (4096, 16384, 69632, 139264, 524288)
+for n in ROWS:
     g = torch.Generator(device="cuda").manual_seed(n)
     x = (torch.rand(n, 256, device="cuda", generator=g) * 2 - 1).contiguous()
     t = torch.rand(n, device="cuda", generator=g)
@@ -26,5 +29,5 @@ for n in (4096, 16384, 69632, 139264, 524288):
             losses = f.step(x, t, steps)
             torch.cuda.synchronize()
             out.append(((time.perf_counter() - t0) / steps * 1e3, float(losses[-1])))
-    print(f"rows {n}: in line {out[0][0]:.4f} / {out[2][0]:.4f} ms, side stream {out[1][0]:.4f} / {out[3][0]:.4f} ms; "
+    print(f"rows {n}: in line {out[0][0]:.4f} / {out[2][0]:.4f} ms, merged {out[1][0]:.4f} / {out[3][0]:.4f} ms; "
           f"final loss equal: {out[0][1] == out[1][1]}")
