@@ -389,8 +389,9 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * tests force the abandon path with 1); key 18 = 64-row tiles for GEMM launches with too few 128-row tiles to fill the chip
  * (1 default); key 19 = cross-layer fused forward for inr_siren_forward / inr_siren_reconstruct (0 default = one launch per layer; 1 =
  * all layers of a 64-row panel in one launch: correct, measured slower, kept as a study -- DESIGN.md); key 20 = the parameter-gradient GEMMs of a fused step as ONE
- * launch behind the input-gradient chain (1 default, applied up to 8,192 rows, where it pays; 0 = one launch per layer, in line;
- * identical bits either way; inr_launch_count counts every GEMM of the merged launch);
+ * launch behind the input-gradient chain, its row splits chosen for the whole launch (1 default, applied below 200,000 rows, where
+ * it pays; 0 = one launch per layer, in line; the gradients' last bits differ between the two: other row ranges per partial sum;
+ * inr_launch_count counts every GEMM of the merged launch);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

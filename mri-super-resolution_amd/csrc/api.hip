@@ -905,13 +905,15 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
 }
 
 
-// ---- the parameter-gradient GEMMs of a small step: one launch for all layers (inr_debug_set(20, 0): one launch per layer) ------
+// ---- the parameter-gradient GEMMs of a step below 200,000 rows: one launch for all layers (inr_debug_set(20, 0): one per layer) --
 // dW_l = dz_l^T act_l depends on the stashed activations and on dz_l only: all of them can wait until the input-gradient chain
-// has produced every dz, and then run as ONE launch (gemm_hp_rc_multi_kernel).  At a few thousand rows a single one fills at
-// most half the chip for 13 us: one launch per layer put four launch boundaries on the critical path, a second stream (the first
-// form of this switch) traded them for event hand-shakes of 7-13 us each (rocprofv3 timeline of a 4,096-row step: 223 us, of
-// which 28 in such gaps).  Measured, ms per step, one launch per layer / merged (tools/side_stream_ab.py): 2,048 rows 0.180 /
-// 0.144, 4,096: 0.223 / 0.200, 8,192: 0.322 / 0.320, 12,288: 0.413 / 0.422, 32,768: 0.671 / 0.679 -- merged up to 8,192 rows.
+// has produced every dz, and then run as ONE launch (gemm_hp_rc_multi_kernel) whose row splits are chosen for the launch as a
+// whole -- one round of blocks over the chip -- instead of for every layer alone.  A rocprofv3 timeline of a 4,096-row step
+// (tools/kt_timeline.py) had shown four 13-20 us launches that each fill half the chip, 28 us of event hand-shakes of the first
+// form of this switch (a second stream), and 16 row splits per layer = 448 blocks writing 57 MB of slabs for `finalize` to read
+// back.  Measured, ms per step, one launch per layer / merged (tools/side_stream_ab.py): 2,048 rows 0.182 / 0.146, 4,096: 0.216
+// / 0.181, 8,192: 0.325 / 0.277, 16,384: 0.454 / 0.381, 32,768: 0.674 / 0.630, 69,632: 1.318 / 1.279, 139,264: 2.431 / 2.408,
+// 262,144: 4.42 / 4.42.  (The last bits of the gradients differ between the two forms: other row ranges per partial sum.)
 tune_int g_hp_side_stream{1};   // (the name of the first form; key 20) identical bits either way
 
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
@@ -980,12 +982,23 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         fin.nparts = blocks;
     }
     // (only where it pays: see above)
-    const bool merge = g_hp_side_stream && L.n_sine > 1 && n <= 8192 && L.n_sine <= hp_param_grad_multi_max();
+    const bool merge = g_hp_side_stream && L.n_sine > 1 && n < 200000 && L.n_sine <= hp_param_grad_multi_max();
     HpParamGradJob jobs[16];
     int njobs = 0;
+    // merged: the launch as a whole should be ONE round of blocks over the chip -- row splits for that, not for each layer alone
+    // (at 4,096 rows 16 splits per layer made 448 blocks that wrote 57 MB of slabs for `finalize` to read back; 9 make 252 and 32)
+    int merged_splits = 1 << 30;
+    if (merge) {
+        long long tiles_all = 0;
+        for (int l = 0; l < L.n_sine; ++l) tiles_all += (long long)((L.fan_out[l] + 127) / 128) * ((L.fan_in[l] + 255) / 256);
+        merged_splits = (int)(256 / tiles_all > 1 ? 256 / tiles_all : 1);
+        const int min_by_len = (int)((n + 16383) / 16384);      // (hp_param_grad_splits: no register accumulation over > 16 k rows)
+        if (merged_splits < min_by_len) merged_splits = min_by_len;
+    }
     for (int l = L.n_sine - 1; l >= 0; --l) {
         const char* dz = reinterpret_cast<const char*>(dact[l]);
-        const int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);
+        int splits = hp_param_grad_splits(n, L.fan_in[l], L.fan_out[l]);     // (what the slab plan reserves: an upper bound)
+        if (splits > merged_splits) splits = merged_splits;
         if (merge) {
             jobs[njobs++] = HpParamGradJob{const_cast<float*>(fin.seg[2 * l].slab), splits, dz, act_hl(l), L.fan_in[l], L.fan_out[l],
                                            dz_scale(l), net.act_scale(l)};

@@ -61,9 +61,9 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
 # GPU time -- three 46,421-row shards take 3 x 0.91 = 2.7 ms where the whole 139,264-row volume takes 2.40.
 STEP_TIME_TABLE_MS = (
     # rows, fused, sharded
-    (4096, 0.2163, 0.2210), (16384, 0.4829, 0.4881), (32768, 0.6897, 0.6965), (46421, 0.9017, 0.9054), (65536, 1.2141, 1.2223),
-    (69632, 1.2954, 1.3006), (98304, 1.7289, 1.7346), (114688, 1.9819, 1.9872), (139264, 2.4013, 2.4007), (262144, 4.3988, 4.4011),
-    (524288, 8.6755, 8.6791),
+    (4096, 0.1806, 0.1842), (16384, 0.3865, 0.3888), (32768, 0.6372, 0.6395), (46421, 0.8670, 0.8707), (65536, 1.1639, 1.1645),
+    (69632, 1.2887, 1.2928), (98304, 1.7301, 1.7287), (114688, 1.9918, 1.9910), (139264, 2.4264, 2.4274),
+    (262144, 4.4722, 4.4645), (524288, 8.8419, 8.8449),
 )
 GRADIENT_BYTES = 3_682_320          # flat fp32 gradient of Siren(256,512,3,1) + the loss slot: one all-reduce per step
 

@@ -52,7 +52,7 @@ def test_gang_sharded_plan_properties():
 def test_measured_step_time_model_and_the_eight_rank_plan():
     """dist.StepTimeModel carries the step times MEASURED on one MI355X (profiles/r03_step_time_table.json): the planner prices
     whole volumes and row shards with it.  A step is not linear in the rows (three 46,421-row shards cost more GPU time than the
-    139,264-row volume they came from), so the 8-rank plan of the reference's 11 patients is worth ~7.1x, not the 7.56x the
+    139,264-row volume they came from), so the 8-rank plan of the reference's 11 patients is worth ~7.2x, not the 7.56x the
     linear model of round 2 promised; whole-volume packing stays at ~6.0x."""
     import json
     import os
@@ -62,7 +62,7 @@ def test_measured_step_time_model_and_the_eight_rank_plan():
     for rows in (4096, 69632, 139264, 524288):                       # the embedded table IS the tracked measurement
         assert m.step_ms(rows) == pytest.approx(measured[rows]["fused_ms_per_step"], rel=2e-3)
     assert m.step_ms(139264, 3) == pytest.approx(measured[46421]["sharded_ms_per_step"] + m.allreduce_ms(3), rel=2e-3)
-    assert 3 * m.step_ms(139264, 3) > 1.25 * m.step_ms(139264)      # sharding costs GPU time
+    assert 3 * m.step_ms(139264, 3) > 1.15 * m.step_ms(139264)      # sharding costs GPU time (1.19 x with the merged parameter-gradient launch, 1.29 x before)
     assert m.step_ms(80000) == pytest.approx((measured[69632]["fused_ms_per_step"] * (98304 - 80000) +
                                               measured[98304]["fused_ms_per_step"] * (80000 - 69632)) / (98304 - 69632), rel=2e-3)
     assert 0.05 < m.allreduce_ms(2) < m.allreduce_ms(3) < m.allreduce_ms(8) < 0.2 and m.allreduce_ms(1) == 0.0
@@ -72,7 +72,7 @@ def test_measured_step_time_model_and_the_eight_rank_plan():
     p8 = inr_dist.plan_fits([r * 2500 for r in rows], 8, shard_time=st)
     assert sorted(j for j, _ in p8["gangs"]) == [8, 9, 10] and [len(r) for _, r in p8["gangs"]] == [3, 3, 2]
     assert all(len(w) == 1 for w in p8["whole"]) and p8["makespan"] == pytest.approx(max(p8["loads"]))
-    assert 6.5 < one / p8["makespan"] < 7.2
+    assert 6.5 < one / p8["makespan"] < 7.4
     lpt = inr_dist.partition_fits([st(j, 1) for j in range(11)], 8)
     assert 5.8 < one / max(sum(st(j, 1) for j in jobs) for jobs in lpt) < 6.2
     p1 = inr_dist.plan_fits([r * 2500 for r in rows], 1, shard_time=st)
