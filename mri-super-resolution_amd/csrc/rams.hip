@@ -739,7 +739,7 @@ int64_t colsum_ws_floats(int64_t n, int C, int G);
 int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, int G, float* slab, hipStream_t st);
 
 size_t rams_conv3d_wgrad_ws_floats(long long nvox) {
-    const size_t a = (size_t)WGRAD_BLOCKS_MAX * CONV_W_FLOATS + (size_t)reduce_tmp_floats(WGRAD_BLOCKS_MAX, CONV_W_FLOATS);
+    const size_t a = (size_t)WGRAD_BLOCKS_MAX * (CONV_W_FLOATS + RC) + (size_t)reduce_tmp_floats(WGRAD_BLOCKS_MAX, CONV_W_FLOATS + RC);
     const size_t b = (size_t)colsum_ws_floats(nvox, RC, 1);
     return (a > b ? a : b) + 64 + 2 * R3_SLOT + 64;      // (+ two max|.| slots for the stand-alone split-fp16 call)
 }
@@ -814,8 +814,13 @@ int rams_conv3d_wgrad_h3(float* gw, float* gb, const float* x, const float* dy, 
         hipLaunchKernelGGL(conv3d_c32_wgrad_h3_kernel, dim3(blocks_per_b, B), dim3(512), 0, st, p);
         INR_LAUNCH_CHECK();
     }
-    if (int rc = launch_reduce_slabs(gw, ws, nslabs, CONV_W_FLOATS, ws + (size_t)nslabs * CONV_W_FLOATS, st)) return rc;
-    if (gb) return launch_colsum(gb, dy, nullptr, (long long)B * ovox, RC, 1, ws, st);
+    // slab rows: [27 x 32 x 32 of gw][32 of gb]; one reduction when the caller keeps gb right behind gw (the training step's folded
+    // gradient buffer does), two otherwise
+    float* tmp = ws + (size_t)nslabs * W3_SLAB;
+    (void)ovox;
+    if (gb == gw + CONV_W_FLOATS) return launch_reduce_slabs_pitched(gw, ws, nslabs, W3_SLAB, W3_SLAB, tmp, st);
+    if (int rc = launch_reduce_slabs_pitched(gw, ws, nslabs, CONV_W_FLOATS, W3_SLAB, tmp, st)) return rc;
+    if (gb) return launch_reduce_slabs_pitched(gb, ws + CONV_W_FLOATS, nslabs, RC, W3_SLAB, tmp, st);
     return 0;
 }
 
