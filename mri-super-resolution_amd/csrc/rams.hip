@@ -536,6 +536,11 @@ static int conv3d_h3(const float* x, float* y, const _Float16* planes, const flo
     return 0;
 }
 
+// may the LDS-staged kernels take this image?  (a 3 x 3 halo of one output column must fit the staged image; one batch element
+// must stay below the 1 GiB their 32-bit buffer offsets and range checks assume -- larger images take the other kernels)
+static inline bool r3l_fits(int D1, int D2, int D3) {
+    return D3 * 9 <= R3L_MAX_HVOX && (long long)(D1 + 2) * (D2 + 2) * (D3 + 2) * RC * 4 < (1ll << 30);
+}
 // patch of the LDS-staged kernel: the most outputs that fit one round of 8 wave tiles (<= 256) whose halo fits the image
 static void r3l_choose_patch(int D3, int O3, int* PO1, int* PO2, int max_hvox = R3L_MAX_HVOX, int max_out = 256) {
     int best = 0, b1 = 1, b2 = 1;
@@ -827,7 +832,7 @@ int rams_conv3d_wgrad_h3(float* gw, float* gb, const float* x, const float* dy, 
 // stand-alone weight gradient (the C-ABI building block): the arithmetic debug key 14 selects, like the training step
 int rams_conv3d_wgrad_auto(float* gw, float* gb, const float* x, const float* dy, int B, int D1, int D2, int D3, int pad, float* ws,
                            hipStream_t st) {
-    if (g_rams_h3 != 2 || D3 * 9 > R3L_MAX_HVOX) return rams_conv3d_wgrad(gw, gb, x, dy, B, D1, D2, D3, pad, ws, st);
+    if (g_rams_h3 != 2 || !r3l_fits(D1, D2, D3) || B > WGRAD_BLOCKS_MAX) return rams_conv3d_wgrad(gw, gb, x, dy, B, D1, D2, D3, pad, ws, st);
     const long long nvox = (long long)B * (D1 + 2 * pad - 2) * (D2 + 2 * pad - 2) * (D3 + 2 * pad - 2);
     float* tail = ws + (rams_conv3d_wgrad_ws_floats(nvox > 0 ? nvox : 1) - (2 * R3_SLOT + 64));
     unsigned* slots = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(tail) + 63) & ~(uintptr_t)63);
@@ -922,7 +927,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
                       unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb) -> int {
         const int k = conv_no++;
         last_nslab = wpb;
-        if (h3 && g_rams_h3 == 2 && D3 * 9 <= R3L_MAX_HVOX)   // (a 3 x 3 halo of one output column must fit the image)
+        if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3))
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
                                  pad, cout, cstride, relu, &last_nslab, st);
         if (h3)
