@@ -250,15 +250,31 @@ __global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__
                                                              const float* __restrict__ gate, const float* __restrict__ res,
                                                              long long per_b, int C, long long total,
                                                              unsigned* amax = nullptr) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    float v = 0.f;
-    if (i < total) {
-        const int c = (int)(i % C);
-        const int b = (int)(i / (per_b * C));
-        v = fmaf(y[i], gate[b * C + c], res[i]);
-        out[i] = v;
+    // grid-stride (launch with nblk_capped): float4 where the channel count allows; one block maximum per block
+    float m = 0.f;
+    if ((C & 3) == 0) {
+        const long long n4 = total >> 2, pb4 = per_b * C >> 2;
+        const int c4n = C >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const int c4 = (int)(i % c4n);
+            const int b = (int)(i / pb4);
+            const float4 g = reinterpret_cast<const float4*>(gate + (long long)b * C)[c4];
+            const float4 a = reinterpret_cast<const float4*>(y)[i];
+            const float4 r = reinterpret_cast<const float4*>(res)[i];
+            const float4 v = make_float4(fmaf(a.x, g.x, r.x), fmaf(a.y, g.y, r.y), fmaf(a.z, g.z, r.z), fmaf(a.w, g.w, r.w));
+            reinterpret_cast<float4*>(out)[i] = v;
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int c = (int)(i % C);
+            const int b = (int)(i / (per_b * C));
+            const float v = fmaf(y[i], gate[b * C + c], res[i]);
+            out[i] = v;
+            m = fmaxf(m, fabsf(v));
+        }
     }
-    if (amax) r3_block_amax(v, amax);
+    if (amax) r3_block_amax(m, amax);
 }
 
 // the same for C = 32 with 16-byte accesses; one batch element per blockIdx.y (no 64-bit divisions)
@@ -448,6 +464,7 @@ __global__ void __launch_bounds__(256) shuffle_sum_kernel(float* __restrict__ ou
 
 // =============================== host orchestration ====================================================
 static inline unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
+static inline unsigned nblk_capped(long long total) { const unsigned b = nblk(total); return b < 2048u ? b : 2048u; }   // grid-stride kernels
 
 struct RamsLayout {
     // offsets (floats) into the packed parameter buffer; see inr_rams_param_offsets
