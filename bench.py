@@ -273,13 +273,14 @@ def rams_leg(reps=3):
     lr = (rng.random((B, P, P, 9)) * 20000).astype(np.float32)
     hr = (rng.random((B, 3 * P, 3 * P, 1)) * 20000).astype(np.float32)
     mask = np.ones((B, 3 * P, 3 * P, 1), np.float32)
-    tr.train_step(lr, hr, mask)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    for _ in range(2):                                     # (the first call sizes the trainer's workspace)
         tr.train_step(lr, hr, mask)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(2 * reps):
+        tr.train_step(lr, hr, mask)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (2 * reps)
     out["train_step"] = {"batch": B, "patch": P, "ms_per_step": dt * 1e3,
                          "tflops": 3 * 265.0e9 * (P * P) / (128 * 128) * B / dt / 1e12}
     return out
