@@ -365,9 +365,10 @@ __global__ void __launch_bounds__(256) add_v4_kernel(float* __restrict__ out, co
 }
 
 // stem with four output channels per thread (one 16-byte store; the 27 inputs are read once per four outputs)
+// (y2, nullable: a second copy of the output -- the long skip keeps the stem output; writing it here saves a device-to-device copy)
 __global__ void __launch_bounds__(256) conv3d_c1_v4_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ bias,
-                                                           int B, int D1, int D2, int D3, unsigned* amax) {
+                                                           int B, int D1, int D2, int D3, unsigned* amax, float* __restrict__ y2 = nullptr) {
     const long long total4 = (long long)B * D1 * D2 * D3 * (RC / 4);
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     float m = 0.f;
@@ -391,6 +392,7 @@ __global__ void __launch_bounds__(256) conv3d_c1_v4_kernel(float* __restrict__ y
                     }
                 }
         reinterpret_cast<f32x4*>(y)[i] = acc;
+        if (y2) reinterpret_cast<f32x4*>(y2)[i] = acc;
 #pragma unroll
         for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[q]));
     }
@@ -1051,10 +1053,9 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         const float* w = c.take(27 * RC); const float* b = c.take(RC);
         io_slot = h3 ? new_slot() : nullptr;
         hipLaunchKernelGGL(conv3d_c1_v4_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * (RC / 4))), dim3(256), 0, st, bufA, xpad,
-                           w, b, B, D1, D2, D3, io_slot);
-        INR_LAUNCH_CHECK();
+                           w, b, B, D1, D2, D3, io_slot, bufR);
+        INR_LAUNCH_CHECK();     // (bufR: the stem output kept for the long skip)
     }
-    INR_HIP(hipMemcpyAsync(bufR, bufA, (size_t)B * D1 * D2 * D3 * RC * 4, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < d->n_rfab; ++i)
         if (int rc = rfab(bufA, D1, D2, D3)) return rc;
     {   // trunk close + long skip (network.py:127-129)
