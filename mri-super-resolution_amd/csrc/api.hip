@@ -1040,6 +1040,32 @@ static int hp_prepare_call(const H3Ctx& ctx, const Layout& L, char* xhl, const f
     return hp_convert(xhl, x, n, L.fan_in[0], sx, st);
 }
 
+// What the last inr_siren_loss_grad_ex call left in a workspace, remembered on the HOST (the call must not sync to look into the
+// device bytes): a REUSE flag is honoured only when this call's (n, fan_in, x) -- and (target, weight) for the statistics -- are
+// the ones the image / slots in that workspace were built from.  A wrong flag (first call, another n, another x) used to run on
+// stale or uninitialised operand images and return wrong gradients with rc 0.
+namespace {
+struct ReuseStamp {
+    const void* ws = nullptr;
+    int64_t n = 0;
+    int fan_in = 0;
+    const void *x = nullptr, *target = nullptr, *weight = nullptr;
+    bool image = false, stats = false;
+};
+std::mutex g_reuse_mu;
+ReuseStamp g_reuse[64];
+unsigned g_reuse_next = 0;
+ReuseStamp* reuse_find(const void* ws, bool create) {      // (caller holds g_reuse_mu)
+    for (auto& s : g_reuse)
+        if (s.ws == ws) return &s;
+    if (!create) return nullptr;
+    ReuseStamp* s = &g_reuse[g_reuse_next++ % 64];
+    *s = ReuseStamp{};
+    s->ws = ws;
+    return s;
+}
+}   // namespace
+
 size_t inr_siren_fit_workspace_bytes(const inr_siren_desc_t* desc, int64_t n) {
     if (check_desc(desc) || n < 1) return 0;
     const Layout L = make_layout(desc);
@@ -1075,6 +1101,10 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
                 "inr_siren_fit: params/grads/x/workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)workspace;
+    {   // this call rebuilds the operand image and the statistics slots of the workspace: a later REUSE flag must not trust them
+        std::lock_guard<std::mutex> lk(g_reuse_mu);
+        if (ReuseStamp* s = reuse_find(workspace, false)) s->image = s->stats = false;
+    }
     std::vector<float*> act(L.n_sine + 1), dact(L.n_sine);
     act[0] = const_cast<float*>(x);
     for (int l = 0; l < L.n_sine; ++l) {
@@ -1148,6 +1178,7 @@ int inr_siren_loss_grad(const inr_siren_desc_t* desc, const float* params, float
                                   stream);
 }
 
+
 int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, float* grads, const float* x,
                            const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
                            void* workspace, size_t workspace_bytes, int flags, void* stream) {
@@ -1176,6 +1207,22 @@ int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, fl
     float* scratch = (float*)((char*)gy + c.out_b);
     H3Ctx h3;
     const bool keep_x = (flags & INR_REUSE_INPUT_IMAGE) != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_reuse_mu);
+        ReuseStamp* s = reuse_find(workspace, flags == 0);
+        if (flags & INR_REUSE_INPUT_IMAGE)
+            INR_REQUIRE(s && s->image && s->n == n && s->fan_in == L.fan_in[0] && s->x == x, INR_E_INVALID,
+                        "inr_siren_loss_grad_ex: INR_REUSE_INPUT_IMAGE, but this workspace does not hold the image of these %lld rows of x",
+                        (long long)n);
+        if (flags & INR_REUSE_TARGET_STATS)
+            INR_REQUIRE(s && s->stats && s->n == n && s->target == target && s->weight == weight, INR_E_INVALID,
+                        "inr_siren_loss_grad_ex: INR_REUSE_TARGET_STATS, but this workspace does not hold the statistics of this target");
+        if (!s) s = reuse_find(workspace, true);
+        const bool hp_path = hp_eligible(desc, L);
+        if (!(flags & INR_REUSE_INPUT_IMAGE)) { s->image = hp_path; s->x = x; s->fan_in = L.fan_in[0]; }
+        if (!(flags & INR_REUSE_TARGET_STATS)) { s->stats = hp_path; s->target = target; s->weight = weight; }
+        s->n = n;
+    }
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, base + c.h3_off);
         if (!keep_x) {

@@ -581,6 +581,7 @@ static int conv3d_mfma(const float* x, float* y, const float* w, const float* bi
 }
 
 int rams_waves_per_b(int B, int ovox);
+long long rams_slab_floats(int B, int ovox_max);
 tune_int g_rams_lds_waves{42};  // LDS-staged kernel: 42 = two blocks of 4 waves x 2 tiles per CU, one staged image each (default: 26.6 ms
                             // per 25 stacks); 8 = 8 waves x 1 tile, two images (29.2 ms); 4 = 4 waves x 2 tiles, two images, one block
                             // per CU (one wave per SIMD hides less latency than the shared weight fragments save); 16 = two-pass
@@ -633,10 +634,15 @@ static int rams_lds_blocks_per_b(int B, int npatch) {
     return blocks < npatch ? blocks : npatch;
 }
 
+#define R3L_SLAB_GUARD(rows_per_b)                                                                                              \
+    INR_REQUIRE(!chan_slab || slab_cap < 0 || (long long)B * (rows_per_b) * RC <= slab_cap, INR_E_INVALID,                       \
+                "RAMS convolution: %d channel-sum slabs per batch element x %d do not fit the %lld floats planned for them",    \
+                (int)(rows_per_b), B, slab_cap)
+
 extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_debug_set_ptr(0, device buffer of 16 x u64)
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
                          const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
-                         int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st) {
+                         int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st, long long slab_cap = -1) {
     Conv3dLdsParams p{};
     p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
@@ -659,21 +665,24 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
         blocks = 512 / B < 1 ? 1 : 512 / B;
         if (blocks > p.np1 * p.np2) blocks = p.np1 * p.np2;
         if (nslab) *nslab = blocks * 4;
+        R3L_SLAB_GUARD(blocks * 4);
         hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true>), dim3(blocks, B), dim3(256), 0, st, p);
     } else if (two_pass) {
         if (nslab) *nslab = blocks * 8;
+        R3L_SLAB_GUARD(blocks * 8);
         hipLaunchKernelGGL(conv3d_c32_lds2_kernel, dim3(blocks, B), dim3(512), 0, st, p);
     } else if (g_rams_lds_waves == 8) {
         if (nslab) *nslab = blocks * 8;
+        R3L_SLAB_GUARD(blocks * 8);
         hipLaunchKernelGGL((conv3d_c32_lds_kernel<8, 1>), dim3(blocks, B), dim3(512), 0, st, p);
     } else {
         if (nslab) *nslab = blocks * 4;
+        R3L_SLAB_GUARD(blocks * 4);
         hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2>), dim3(blocks, B), dim3(256), 0, st, p);
     }
     INR_LAUNCH_CHECK();
     return 0;
 }
-
 static inline int rams_conv3d_count(const inr_rams_desc_t* d) { return 2 * d->n_rfab + 1 + 3 * (d->channels / 3) + 1; }
 constexpr int R3_MAX_CONVS = 96;
 struct R3SplitJobs {
@@ -934,10 +943,24 @@ int rams_waves_per_b(int B, int ovox) {
     return blocks * 8;
 }
 
+// Channel-sum slab region of a forward / training pass: [B][rows][32] floats, where `rows` is the most any producer writes per
+// batch element -- 8 per block of the f32-input / global-operand kernels (rams_waves_per_b), 4 or 8 per block of the LDS-staged
+// kernels, whose default (key 15 = 42) launches up to 512 / B blocks, and the 64 phases of chan_partial_kernel / the gate
+// backward.  (Round 3 sized the inference region by the first term only: at B = 20, 22, 24, 26, 29, 30 the 42-kernel wrote into
+// the gate rows behind it, from B = 33 on past the pad.)  + 4096: the [B][32] gates live in the last 2,048 floats.
+long long rams_slab_floats(int B, int ovox_max) {
+    const int per_b_lds = (512 / B < 1 ? 1 : 512 / B) * 8;
+    int rows = rams_waves_per_b(B, ovox_max);
+    if (rows < per_b_lds) rows = per_b_lds;
+    if (rows < 64) rows = 64;
+    long long gates = (long long)B * RC;
+    return (long long)B * rows * RC + 2048 + (gates > 2048 ? gates : 2048);
+}
+
 size_t rams_workspace_floats(const inr_rams_desc_t* d, int B, int H, int W) {
     const long long T = d->channels;
     const long long big = (long long)B * (H + 4) * (W + 4) * T * RC;      // largest 5-D activation (padded reduction stage)
-    const long long slab = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * (int)T) * RC + 4096;
+    const long long slab = rams_slab_floats(B, (H + 4) * (W + 4) * (int)T);
     const long long small = (long long)B * (H + 2) * (W + 2) * T * 4 + (long long)B * H * W * d->scale * d->scale * 2;
     // split-fp16 inference: hi/lo planes of every 32 -> 32 kernel + scale slots
     const long long h3 = (long long)rams_conv3d_count(d) * (R3_LAYER_HALVES / 2) + 1024 +
@@ -956,8 +979,10 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     float* bufR = bufC + big;       // trunk residual (stem output)
     float* bufP = bufR + big;       // padded copies
     float* slab = bufP + big;
-    const long long slab_floats = (long long)B * rams_waves_per_b(B, (H + 4) * (W + 4) * T) * RC + 4096;
-    float* gate = slab + slab_floats - 2048;         // [B][32]
+    const long long slab_floats = rams_slab_floats(B, (H + 4) * (W + 4) * T);
+    const long long gate_floats = (long long)B * RC > 2048 ? (long long)B * RC : 2048;
+    const long long slab_cap = slab_floats - gate_floats - 2048;   // what the channel-sum producers may use
+    float* gate = slab + slab_floats - gate_floats;  // [B][32]
     float* xn = slab + slab_floats;                  // normalised input [B][H][W][T]
     float* xpad = xn + (long long)B * H * W * T;     // reflect-padded [B][H+2][W+2][T]
     float* g1 = xpad + (long long)B * (H + 2) * (W + 2) * T;
@@ -1004,7 +1029,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         last_nslab = wpb;
         if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3))
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
-                                 pad, cout, cstride, relu, &last_nslab, st);
+                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap);
         if (h3)
             return conv3d_h3(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3, pad,
                              cout, cstride, relu, wpb, st);

@@ -11,6 +11,7 @@
 // revolutions), so results agree with the layer-by-layer path to rounding.
 // Eligibility (host): hidden in {32, 64}, in_features <= 32, out_features == 1.
 #include "common.h"
+#include <atomic>
 
 namespace inr {
 
@@ -960,10 +961,24 @@ static int multi_capacity_of() {
     return prop.multiProcessorCount * per_cu;
 }
 static int multi_capacity(int H, int rows) {
-    static int cap[3] = {0, 0, 0};
+    // per DEVICE (a process may drive several, or partitions of different size) and race-free: relaxed atomics -- two threads
+    // that both find 0 compute the same value
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cap[MAX_DEV][3];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
     const int k = (H == 32) ? 0 : (rows == 32 ? 1 : 2);
-    if (!cap[k]) cap[k] = (k == 0) ? multi_capacity_of<32, 64>() : (k == 1) ? multi_capacity_of<64, 32>() : multi_capacity_of<64, 64>();
-    return cap[k];
+    auto compute = [&]() { return (k == 0) ? multi_capacity_of<32, 64>() : (k == 1) ? multi_capacity_of<64, 32>() : multi_capacity_of<64, 64>(); };
+    if (dev < 0 || dev >= MAX_DEV) return compute();
+    int c = cap[dev][k].load(std::memory_order_relaxed);
+    if (!c) {
+        c = compute();
+        cap[dev][k].store(c, std::memory_order_relaxed);
+    }
+    return c;
 }
 
 static int multi_rows(const inr_siren_desc_t* d, int64_t n) {

@@ -158,7 +158,7 @@ def plan_fits(costs: Sequence[float], world_size: int, shard_overhead: float = 0
     return min(candidates, key=lambda p: p["makespan"])     # ties: the earlier (simpler) candidate
 
 
-_GROUPS: Dict[tuple, object] = {}
+_GROUPS: Dict[object, object] = {}
 
 
 def rank_group(ranks: Sequence[int]):
@@ -168,6 +168,12 @@ def rank_group(ranks: Sequence[int]):
     ranks = tuple(int(r) for r in ranks)
     if len(ranks) <= 1:
         return None
+    # keyed on the IDENTITY of the default group: after destroy_process_group + a new init (tests, notebooks) the old handles
+    # point into a dead group, and a cache hit on some ranks only would skip the collective new_group on those ranks
+    world = dist.group.WORLD
+    if _GROUPS.get("world") is not world:
+        _GROUPS.clear()
+        _GROUPS["world"] = world
     key = (dist.get_world_size(), ranks)
     if key not in _GROUPS:
         _GROUPS[key] = dist.new_group(list(ranks))

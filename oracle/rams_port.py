@@ -104,8 +104,14 @@ def depth_to_space(x, bs):
     return x.reshape(b, h, w, bs, bs, co).permute(0, 1, 3, 2, 4, 5).reshape(b, h * bs, w * bs, co)
 
 
-def rams_graph(params, x, scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
-    """network.py:110-155 on a torch tensor x [B, H, W, channels] (any float dtype; differentiable)."""
+def rams_graph(params, x, scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12, shuffle=None):
+    """network.py:110-155 on a torch tensor x [B, H, W, channels] (any float dtype; differentiable).
+
+    ``shuffle``: block size of the two ``depth_to_space`` calls.  The reference writes the literal 3 (network.py:141,148) beside
+    ``Conv3D(scale**2)``, so with the reference's own semantics (``shuffle=None`` -> 3) any ``scale != 3`` is a TensorFlow shape
+    error (4 or 16 channels are not a multiple of 9).  ``shuffle=scale`` is the build-side reading "the 3 means scale" that
+    BASELINE config 3's "x4" needs; tests of scale 2 / 4 pass it explicitly."""
+    bs = 3 if shuffle is None else int(shuffle)
     k3, k2 = (kernel_size,) * 3, (kernel_size,) * 2
     xn = (x - MEAN) / STD                                                          # normalize, :21-23
     g_res = xn
@@ -120,18 +126,18 @@ def rams_graph(params, x, scale=3, filters=32, kernel_size=3, channels=9, r=8, N
         y = _attention_block(y, params, f"red{i}/rfab", filters, k3, r)
         y = torch.relu(_conv(y, params, f"red{i}/conv", filters, (3, 3, 3), "valid"))
     y = _conv(y, params, "up", scale ** 2, (3, 3, 3), "valid")[..., 0, :]            # upscaling, :139-141
-    y = depth_to_space(y, 3)                                                       # the reference hard-codes 3, :141
+    y = depth_to_space(y, bs)                                                      # the reference hard-codes 3, :141
     g = _reflect_hw(g_res)                                                         # global path, :144-148
     g = _attention_block(g, params, "rtab", 9, k2, r)                              # RTAB(x, 9, ...), :146
-    g = depth_to_space(_conv(g, params, "global", scale ** 2, (3, 3), "valid"), 3)
+    g = depth_to_space(_conv(g, params, "global", scale ** 2, (3, 3), "valid"), bs)
     return (y + g) * STD + MEAN                                                    # denormalize, :25-27
 
 
-def rams_layer_specs(scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12):
+def rams_layer_specs(scale=3, filters=32, kernel_size=3, channels=9, r=8, N=12, shuffle=None):
     """[(name, kernel shape, cin, cout)] discovered by one dry run of ``rams_graph`` on an 8 x 8 input (no table)."""
     rec = _Recorder()
     with torch.no_grad():
-        rams_graph(rec, torch.zeros(1, 8, 8, channels), scale, filters, kernel_size, channels, r, N)
+        rams_graph(rec, torch.zeros(1, 8, 8, channels), scale, filters, kernel_size, channels, r, N, shuffle)
     return rec.order
 
 

@@ -57,6 +57,22 @@ def test_host_only_entry_points_without_gpu():
     assert lib.inr_adam_step(None, None, None, None, 4, 1, 1e-4, 0.9, 0.999, 1e-8, None) == -1
 
 
+def test_reuse_flags_are_refused_on_a_workspace_that_does_not_hold_the_image():
+    """inr_siren_loss_grad_ex(flags): INR_REUSE_INPUT_IMAGE / INR_REUSE_TARGET_STATS on a workspace whose last call was not for
+    the same (n, x) / (target, weight) returns INR_E_INVALID before any device work (a host-side stamp per workspace)."""
+    lib = _lib.lib()
+    desc = _lib.SirenDesc(256, 512, 3, 1, 30.0, 30.0)
+    n = 4096
+    wsb = lib.inr_siren_fit_workspace_bytes(ctypes.byref(desc), n)
+    fake = lambda k: ctypes.c_void_p(0x7000_0000_0000 + 4096 * k)      # never dereferenced: the call fails in validation
+    for flags in (1, 2, 3):
+        rc = lib.inr_siren_loss_grad_ex(ctypes.byref(desc), fake(1), fake(2), fake(3), fake(4), None, n, 0, fake(5), fake(6), wsb,
+                                        flags, None)
+        assert rc == -1 and b"REUSE" in lib.inr_last_error()
+    assert lib.inr_siren_loss_grad_ex(ctypes.byref(desc), fake(1), fake(2), fake(3), fake(4), None, n, 0, fake(5), fake(6), wsb,
+                                      4, None) == -1 and b"unknown flags" in lib.inr_last_error()
+
+
 @pytest.mark.parametrize("flavor", ["SRDWI", "INRmodel"])
 def test_siren_init_is_bit_identical_to_reference(golden, flavor):
     g = golden("siren512_step0.npz")

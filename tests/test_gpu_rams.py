@@ -92,6 +92,40 @@ def test_forward_matches_oracle(B, H, W, conv_mode):
     assert pt.min() >= 0 and pt.max() <= 65536
 
 
+@pytest.mark.parametrize("scale", [2, 4])
+def test_scale_other_than_three(scale):
+    """``scale`` is plumbed through RamsDesc, the head convolutions (scale^2 output channels) and the pixel shuffle.  The
+    reference writes ``depth_to_space(x, 3)`` literally (network.py:141,148) -- any other scale is a TensorFlow shape error there
+    -- so the oracle is asked for the generalised reading ``shuffle=scale`` (BASELINE config 3 says "x4")."""
+    kw = dict(scale=scale, N=2)
+    params = R.init_rams_params(seed=6, perturb_g=True, shuffle=scale, **kw)
+    model = rams.RAMS(scale, 32, 3, 9, 8, 2, params=params)
+    assert rams.rams_layer_specs(**kw) == R.rams_layer_specs(shuffle=scale, **kw)
+    x = (np.random.default_rng(scale).random((2, 14, 17, 9)) * 40000).astype(np.float32)
+    want = R.rams_forward(params, x, shuffle=scale, **kw)
+    got = model(x).cpu().numpy()
+    assert got.shape == (2, scale * 14, scale * 17, 1)
+    assert O.rel_l2((got - R.MEAN) / R.STD, (want - R.MEAN) / R.STD) < 5e-5
+    with pytest.raises(Exception):                      # the reference's own reading: a shape error
+        R.rams_forward(params, x, **kw)
+
+
+@pytest.mark.parametrize("B", [20, 29, 33])
+def test_batch_sizes_with_an_odd_block_count(B):
+    """floor(512 / B) odd: the default LDS-staged kernel writes 4 * floor(512 / B) channel-sum slabs per batch element; round 3
+    planned 8 * floor(256 / B) and the surplus rows landed in the attention gates (B = 20 .. 30) or past the pad (B >= 33).
+    Batch elements are independent, so every row of the batched forward must equal the same stack run on its own."""
+    params = R.init_rams_params(seed=8, perturb_g=True, N=1)
+    model = rams.RAMS(3, 32, 3, 9, 8, 1, params=params)
+    x = (np.random.default_rng(B).random((B, 40, 40, 9)) * 30000 + 500).astype(np.float32)
+    got = model(x).cpu().numpy()
+    for b in (0, B // 2, B - 2, B - 1):
+        single = model(x[b:b + 1]).cpu().numpy()
+        assert O.rel_l2(got[b:b + 1], single) < 1e-6, b
+    want = R.rams_forward(params, x[B - 2:], N=1)
+    assert O.rel_l2((got[B - 2:] - R.MEAN) / R.STD, (want - R.MEAN) / R.STD) < 5e-5
+
+
 def test_smaller_network_and_default_init():
     model = rams.RAMS(3, 32, 3, 9, 8, 2, seed=3)         # N = 2 RFABs, Keras-style default init
     x = (np.random.default_rng(0).random((2, 12, 14, 9)) * 65535).astype(np.float32)
