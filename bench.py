@@ -94,7 +94,8 @@ def cpu_baseline(n_sweep, steps, warmup, B_np, vol, thread_counts):
     dt = time.perf_counter() - t0
     return {"value": n_all * steps / dt, "unit": "voxels/s", "cores": best_nt, "kind": "port",
             "sample": f"all {n_all} LR rows of the synthetic 128^3 fit, {steps} timed full-batch steps after {warmup} warm-up at "
-                      f"{best_nt} threads (BASELINE.md section 3 asks for 5 + 20: bounded here to keep the run within minutes; "
+                      f"{best_nt} threads (BASELINE.md section 3 asks for 5 + 20: bounded here to keep the run within minutes -- the "
+                      f"5 + 20 form, run once on the GPU box's host, is profiles/r04_cpu_baseline.json: 73.4 k voxels/s at 32 threads; "
                       f"thread count picked by a 2-step sweep on {n_sweep} rows), torch {torch.__version__} CPU "
                       f"({os.cpu_count()} logical CPUs visible)",
             "seconds": dt, "ms_per_step": dt / steps * 1e3, "thread_sweep": sweep}
@@ -617,7 +618,8 @@ def main():
         out["hybrid_fit"] = hybrid_fit_leg()
     if not args.no_cpu_baseline and world == 1:
         ncpu = os.cpu_count() or 1
-        sweep = sorted({max(1, ncpu // 4), max(1, ncpu // 2)}) if ncpu >= 16 else [ncpu]
+        # (profiles/r04_cpu_baseline.json: 5 + 20 steps with a sweep over 32 .. 256 threads on the 2 x 64-core host -- 32 threads win)
+        sweep = sorted({max(1, ncpu // 8), max(1, ncpu // 4)}) if ncpu >= 16 else [ncpu]
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_steps, args.cpu_warmup, B_np, vol, sweep)
         out["speedup_vs_cpu_baseline"] = out["value"] / world / out["cpu_baseline"]["value"]
     print(json.dumps(out))

@@ -239,6 +239,22 @@ int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, fl
                         const float* target, const float* weight, int64_t n, int64_t count_total, float* loss,
                         void* workspace, size_t workspace_bytes, int flags, void* stream);
 
+/* (f) the reference's OWN loop, unmodified (superresDWI.py:132-138): `out = INR(x)` -> torch forms the loss -> `loss.backward()`
+ * -> `torch.optim.Adam.step()`.  The autograd Function behind `Siren.forward` (replaces SRDWI.py:87-91 + autograd's backward of
+ * it) calls these two instead of the layer-by-layer entry points when inr_siren_hp_eligible(desc) != 0:
+ *   inr_siren_forward_train  y[n] = network(x) on the pre-split kernels of the fused fit, every layer's stash kept in `workspace`
+ *                            (the last sine layer stashes z + b only); flags: INR_REUSE_INPUT_IMAGE as above.
+ *   inr_siren_backward_train grads (flat, network order, inr_siren_param_count floats; every element written) = d(sum_r gy[r] y[r])
+ *                            / d params from the stash of the LAST inr_siren_forward_train on this workspace (INR_E_INVALID when
+ *                            there is none, or n differs); gy = dL/dy [n] as autograd hands it over.  `params` must still hold
+ *                            the values the forward ran on.  One backward per forward.
+ * Workspace: inr_siren_fit_workspace_bytes(desc, n).  Both only enqueue. */
+int inr_siren_hp_eligible(const inr_siren_desc_t* desc);
+int inr_siren_forward_train(const inr_siren_desc_t* desc, const float* params, const float* x, float* y, int64_t n,
+                            void* workspace, size_t workspace_bytes, int flags, void* stream);
+int inr_siren_backward_train(const inr_siren_desc_t* desc, const float* params, float* grads, const float* gy, int64_t n,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- a-12: end-of-fit metrics on the device (fp64 accumulation, fixed-order reductions) -----------------
  * workspace for all three image metrics: inr_metric_workspace_bytes(n_images).
  * inr_psnr:   out[b] (double) = 10*log10(data_range^2 / mean((x_b - y_b)^2)); x, y are [n_images][per_image] fp32.

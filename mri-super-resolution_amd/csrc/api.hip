@@ -107,11 +107,12 @@ int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char*
 int hp_param_grad_multi_max();
 int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStream_t stream);
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
-                    float clamp_min, hipStream_t stream);
+                    float clamp_min, hipStream_t stream, bool from_z = false, float omega = 0.f);
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
                  int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z = false,
-                 float omega = 0.f);
+                 float omega = 0.f, const float* g_ext = nullptr);
+int hp_head_bound_ext(float* head_bound, const unsigned* gmax, const float* head_W, int hidden, float omega, hipStream_t stream);
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
                           int out_f, hipStream_t stream, const H3Args* h3 = nullptr);
 int launch_mgrid(float* out, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, hipStream_t st);
@@ -919,18 +920,34 @@ tune_int g_hp_side_stream{1};   // (the name of the first form; key 20) identica
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
 // dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
 // here: every producer leaves its slab rows in `slabs` and `fin` describes them (the caller finishes with launch_finalize).
-static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
-                                   std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* slabs,
-                                   const float* target, const float* weight, int64_t n, int64_t count_total, float* loss_dst,
-                                   hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin) {
+// forward of the sine layers (stash kept for the backward pass); z_head: the last layer stashes z + b only (HPE_Z)
+static int hp_forward_pass(const inr_siren_desc_t* d, const Layout& L, const float* params, std::vector<float*>& act,
+                           std::vector<float*>& dact, const char* xhl, int64_t n, hipStream_t st, const H3Ctx& ctx, bool z_head) {
+    const HpNet net{&ctx, &L};
+    const int head = L.n_sine;
+    auto act_hl = [&](int l) -> const char* { return l == 0 ? xhl : reinterpret_cast<const char*>(act[l]); };
+    for (int l = 0; l < L.n_sine; ++l) {
+        const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
+        if (int rc = hp_sine_forward(reinterpret_cast<char*>(act[l + 1]), dact[l], act_hl(l), net.w_hl(l), params + L.b_off[l], n,
+                                     L.fan_in[l], L.fan_out[l], omega, net.act_scale(l), net.w_scale(l), 0, st,
+                                     z_head && l == head - 1))
+            return rc;
+    }
+    return 0;
+}
+
+// head step + backward of every layer.  The loss gradient is formed here from (target, weight) -- the fused fit -- or taken from
+// the caller (g_ext = dL/dy, the autograd path; target / weight unused, no loss).  Gradients are NOT reduced here: every producer
+// leaves its slab rows in `slabs` and `fin` describes them (the caller finishes with launch_finalize).
+static int hp_backward_pass(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
+                            std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* slabs,
+                            const float* target, const float* weight, const float* g_ext, int64_t n, int64_t count_total,
+                            float* loss_dst, hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin, bool z_head) {
     const int H = d->hidden_features, head = L.n_sine;
     const HpNet net{&ctx, &L};
     const HpSlabPlan plan = hp_slab_plan(L, n);
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
     const float omega_last = (head - 1 == 0) ? d->first_omega : d->hidden_omega;
-    const HpHeadBoundArgs hb{params + L.w_off[head], params + L.b_off[head], ctx.slots + 25, weight ? ctx.slots + 26 : nullptr,
-                             inv, omega_last};
-    if (int rc = hp_refresh_weights(net, params, st, &hb)) return rc;
     fin = FinalizeJob{};
     fin.nseg = 2 * (head + 1);
     for (int k = 0; k < fin.nseg; ++k) {
@@ -945,16 +962,6 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
     fin.loss_out = loss_dst;
     fin.loss_scale = inv;
     auto act_hl = [&](int l) -> const char* { return l == 0 ? xhl : reinterpret_cast<const char*>(act[l]); };
-    // the output of the LAST sine layer feeds nothing but the head: that layer stashes z + b only (one fp32 matrix instead
-    // of act + omega cos) and the head step forms sin / cos itself -- 2.1 GB less HBM traffic per step at N = 524,288
-    const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
-    for (int l = 0; l < L.n_sine; ++l) {
-        const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
-        if (int rc = hp_sine_forward(reinterpret_cast<char*>(act[l + 1]), dact[l], act_hl(l), net.w_hl(l), params + L.b_off[l], n,
-                                     L.fan_in[l], L.fan_out[l], omega, net.act_scale(l), net.w_scale(l), 0, st,
-                                     z_head && l == head - 1))
-            return rc;
-    }
     // scale of dz_l: the head's bound for the last sine layer, else measured max|dz_{l+1}| * wnorm_{l+1} * omega_l
     auto dz_scale = [&](int l) {
         HpScale s;
@@ -975,7 +982,7 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
         if (int rc = hp_head_step(reinterpret_cast<char*>(dact[head - 1]), const_cast<float*>(fin.seg[kb].slab),
                                   const_cast<float*>(fin.seg[kw].slab), part_loss, const_cast<float*>(fin.seg[kg].slab),
                                   act_hl(head), dact[head - 1], params + L.w_off[head], params + L.b_off[head], target, weight,
-                                  n, H, count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last))
+                                  n, H, count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last, g_ext))
             return rc;
         fin.seg[kb].nslabs = fin.seg[kw].nslabs = fin.seg[kg].nslabs = blocks;
         fin.part_loss = part_loss;
@@ -1022,6 +1029,25 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
     return 0;
 }
 
+static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
+                                   std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* slabs,
+                                   const float* target, const float* weight, int64_t n, int64_t count_total, float* loss_dst,
+                                   hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin) {
+    const int head = L.n_sine;
+    const HpNet net{&ctx, &L};
+    const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
+    const float omega_last = (head - 1 == 0) ? d->first_omega : d->hidden_omega;
+    const HpHeadBoundArgs hb{params + L.w_off[head], params + L.b_off[head], ctx.slots + 25, weight ? ctx.slots + 26 : nullptr,
+                             inv, omega_last};
+    if (int rc = hp_refresh_weights(net, params, st, &hb)) return rc;
+    // the output of the LAST sine layer feeds nothing but the head: that layer stashes z + b only (one fp32 matrix instead
+    // of act + omega cos) and the head step forms sin / cos itself -- 2.1 GB less HBM traffic per step at N = 524,288
+    const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
+    if (int rc = hp_forward_pass(d, L, params, act, dact, xhl, n, st, ctx, z_head)) return rc;
+    return hp_backward_pass(d, L, params, grads, act, dact, xhl, slabs, target, weight, nullptr, n, count_total, loss_dst, st, ctx,
+                            fin, z_head);
+}
+
 // per call: scales of the network input and of the targets, HL32 image of x
 static int hp_prepare_call(const H3Ctx& ctx, const Layout& L, char* xhl, const float* x, const float* target,
                            const float* weight, int64_t n, int out_f, hipStream_t st, int64_t n_acq = 1, bool keep_x = false,
@@ -1051,6 +1077,7 @@ struct ReuseStamp {
     int fan_in = 0;
     const void *x = nullptr, *target = nullptr, *weight = nullptr;
     bool image = false, stats = false;
+    bool fwd_train = false;      // an inr_siren_forward_train stash is pending (inr_siren_backward_train consumes it)
 };
 std::mutex g_reuse_mu;
 ReuseStamp g_reuse[64];
@@ -1103,7 +1130,7 @@ int inr_siren_fit_cycle(const inr_siren_desc_t* desc, float* params, float* grad
     char* base = (char*)workspace;
     {   // this call rebuilds the operand image and the statistics slots of the workspace: a later REUSE flag must not trust them
         std::lock_guard<std::mutex> lk(g_reuse_mu);
-        if (ReuseStamp* s = reuse_find(workspace, false)) s->image = s->stats = false;
+        if (ReuseStamp* s = reuse_find(workspace, false)) s->image = s->stats = s->fwd_train = false;
     }
     std::vector<float*> act(L.n_sine + 1), dact(L.n_sine);
     act[0] = const_cast<float*>(x);
@@ -1242,6 +1269,126 @@ int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, fl
     }
     return fit_forward_backward(desc, L, params, grads, act, dact, y, gy, scratch, target, weight, n, count_total, loss,
                                 (hipStream_t)stream, &h3);
+}
+
+// ---- the autograd path on the fused fit's kernels (include/inrhip.h (f)) ------------------------------------------------------
+int inr_siren_hp_eligible(const inr_siren_desc_t* desc) {
+    if (check_desc(desc)) return 0;
+    const Layout L = make_layout(desc);
+    return hp_eligible(desc, L) ? 1 : 0;
+}
+
+namespace {
+struct TrainCarve {
+    std::vector<float*> act, dact;
+    float* scratch;
+    char* xhl;
+    H3Ctx h3;
+};
+// (the carve of inr_siren_fit: both passes of a step must see the same one)
+int train_carve(TrainCarve& t, const inr_siren_desc_t* desc, const Layout& L, const float* x, int64_t n, void* workspace,
+                size_t workspace_bytes, const char* who) {
+    const FitCarve c = fit_carve(desc, L, n);
+    INR_REQUIRE(workspace && workspace_bytes >= c.total, INR_E_WORKSPACE, "%s: workspace too small (%zu < %zu)", who, workspace_bytes,
+                c.total);
+    char* base = (char*)workspace;
+    t.act.assign(L.n_sine + 1, nullptr);
+    t.dact.assign(L.n_sine, nullptr);
+    t.act[0] = const_cast<float*>(x);
+    for (int l = 0; l < L.n_sine; ++l) {
+        t.act[l + 1] = (float*)(base + (size_t)l * c.act_b);
+        t.dact[l] = (float*)(base + (size_t)(L.n_sine + l) * c.act_b);
+    }
+    float* y = (float*)(base + 2 * (size_t)L.n_sine * c.act_b);
+    float* gy = (float*)((char*)y + c.out_b);
+    t.scratch = (float*)((char*)gy + c.out_b);
+    t.xhl = base + c.xhl_off;
+    t.h3 = h3_make_ctx(L, base + c.h3_off);
+    return 0;
+}
+}   // namespace
+
+int inr_siren_forward_train(const inr_siren_desc_t* desc, const float* params, const float* x, float* y, int64_t n,
+                            void* workspace, size_t workspace_bytes, int flags, void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE((flags & ~INR_REUSE_INPUT_IMAGE) == 0, INR_E_INVALID, "inr_siren_forward_train: unknown flags 0x%x", flags);
+    INR_REQUIRE(params && x && y, INR_E_INVALID, "inr_siren_forward_train: null pointer");
+    INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_forward_train: bad row count %lld", (long long)n);
+    const Layout L = make_layout(desc);
+    INR_REQUIRE(hp_eligible(desc, L), INR_E_INVALID, "inr_siren_forward_train: network shape not served by the pre-split kernels "
+                "(ask inr_siren_hp_eligible)");
+    INR_REQUIRE(aligned16(workspace) && aligned16(params) && aligned16(x), INR_E_ALIGN,
+                "inr_siren_forward_train: params/x/workspace must be 16-byte aligned");
+    TrainCarve t;
+    if (int rc = train_carve(t, desc, L, x, n, workspace, workspace_bytes, "inr_siren_forward_train")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bool keep_x = (flags & INR_REUSE_INPUT_IMAGE) != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_reuse_mu);
+        ReuseStamp* s = reuse_find(workspace, !keep_x);
+        if (keep_x)
+            INR_REQUIRE(s && s->image && s->n == n && s->fan_in == L.fan_in[0] && s->x == x, INR_E_INVALID,
+                        "inr_siren_forward_train: INR_REUSE_INPUT_IMAGE, but this workspace does not hold the image of these %lld rows of x",
+                        (long long)n);
+        s->image = true;
+        s->x = x;
+        s->fan_in = L.fan_in[0];
+        s->n = n;
+        s->stats = false;
+        s->fwd_train = true;
+    }
+    if (!keep_x) {
+        if (int rc = h3_tensor_amax(t.h3.slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
+        HpScale sx;
+        sx.meas = t.h3.slots + 24;
+        sx.mul = 1.f;
+        if (int rc = hp_convert(t.xhl, x, n, L.fan_in[0], sx, st)) return rc;
+    }
+    const HpNet net{&t.h3, &L};
+    if (int rc = hp_refresh_weights(net, params, st, nullptr)) return rc;      // (also zeroes this step's dz maxima)
+    const int head = L.n_sine;
+    const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
+    if (int rc = hp_forward_pass(desc, L, params, t.act, t.dact, t.xhl, n, st, t.h3, z_head)) return rc;
+    const float omega_last = (head - 1 == 0) ? desc->first_omega : desc->hidden_omega;
+    return hp_head_forward(y, z_head ? reinterpret_cast<const char*>(t.dact[head - 1]) : reinterpret_cast<const char*>(t.act[head]),
+                           params + L.w_off[head], params + L.b_off[head], n, desc->hidden_features, 0, 0.f, st, z_head, omega_last);
+}
+
+int inr_siren_backward_train(const inr_siren_desc_t* desc, const float* params, float* grads, const float* gy, int64_t n,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(desc)) return rc;
+    INR_REQUIRE(params && grads && gy, INR_E_INVALID, "inr_siren_backward_train: null pointer");
+    INR_REQUIRE(n >= 1 && n <= MAX_ROWS, INR_E_INVALID, "inr_siren_backward_train: bad row count %lld", (long long)n);
+    const Layout L = make_layout(desc);
+    INR_REQUIRE(hp_eligible(desc, L), INR_E_INVALID, "inr_siren_backward_train: network shape not served by the pre-split kernels");
+    INR_REQUIRE(aligned16(workspace) && aligned16(params) && aligned16(grads), INR_E_ALIGN,
+                "inr_siren_backward_train: params/grads/workspace must be 16-byte aligned");
+    const void* x = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reuse_mu);
+        ReuseStamp* s = reuse_find(workspace, false);
+        INR_REQUIRE(s && s->fwd_train && s->n == n, INR_E_INVALID,
+                    "inr_siren_backward_train: no inr_siren_forward_train of %lld rows is pending on this workspace", (long long)n);
+        s->fwd_train = false;       // (the backward overwrites the stash with dz: one backward per forward)
+        x = s->x;
+    }
+    TrainCarve t;
+    if (int rc = train_carve(t, desc, L, (const float*)x, n, workspace, workspace_bytes, "inr_siren_backward_train")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int head = L.n_sine;
+    const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
+    const HpNet net{&t.h3, &L};
+    const float omega_last = (head - 1 == 0) ? desc->first_omega : desc->hidden_omega;
+    // the scale of the head's dz: max|gy| x max|w_head| x omega (measured: gy is the caller's)
+    if (int rc = h3_tensor_amax(t.h3.slots + 25, gy, (long long)n * desc->out_features, st, 0u)) return rc;
+    if (int rc = hp_head_bound_ext(net.head_bound(), t.h3.slots + 25, params + L.w_off[head], desc->hidden_features, omega_last, st))
+        return rc;
+    FinalizeJob fin;
+    float* loss_sink = t.scratch + hp_slab_plan(L, n).loss_sink;
+    if (int rc = hp_backward_pass(desc, L, params, grads, t.act, t.dact, t.xhl, t.scratch, nullptr, nullptr, gy, n, 1, loss_sink, st,
+                                  t.h3, fin, z_head))
+        return rc;
+    return launch_finalize(fin, 0, 0.0, 0.0, 0.0, 0.0, st);
 }
 
 // ---- metrics ---------------------------------------------------------------------------------------------

@@ -1500,18 +1500,37 @@ int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStr
 }
 
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
-                    float clamp_min, hipStream_t stream) {
+                    float clamp_min, hipStream_t stream, bool from_z, float omega) {
     long long blocks = (n + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     const dim3 grid((unsigned)blocks), block(256);
     ProfScope ps(KC_OTHER, stream);
+    if (from_z) {
+        switch (hidden) {
+            case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
+            case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
+            case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
+            case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
+            default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_forward: hidden = %d", hidden);
+        }
+        INR_LAUNCH_CHECK();
+        return 0;
+    }
     switch (hidden) {
-        case 128: hipLaunchKernelGGL(hp_head_forward_kernel<2>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
-        case 256: hipLaunchKernelGGL(hp_head_forward_kernel<4>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
-        case 512: hipLaunchKernelGGL(hp_head_forward_kernel<8>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
-        case 1024: hipLaunchKernelGGL(hp_head_forward_kernel<16>, grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min); break;
+        case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
+        case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
+        case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
+        case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
         default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_forward: hidden = %d", hidden);
     }
+    INR_LAUNCH_CHECK();
+    return 0;
+}
+
+// bound of the head's dz for an external dL/dy (the autograd path): gmax = slot holding max|g|
+int hp_head_bound_ext(float* head_bound, const unsigned* gmax, const float* head_W, int hidden, float omega, hipStream_t stream) {
+    ProfScope ps(KC_OTHER, stream);
+    hipLaunchKernelGGL(hp_head_bound_ext_kernel, dim3(1), dim3(256), 0, stream, head_bound, gmax, head_W, hidden, omega);
     INR_LAUNCH_CHECK();
     return 0;
 }
@@ -1531,7 +1550,8 @@ int64_t hp_head_blocks(int64_t n) {
 // slab_b / slab_w: [blocks][hidden], part_loss / part_g: [blocks], blocks = hp_head_blocks(n)
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
-                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z, float omega) {
+                 int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z, float omega,
+                 const float* g_ext) {
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
     const int rpb = hp_head_rows_per_block(n);
     const dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
@@ -1540,10 +1560,10 @@ int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, fl
     do {                                                                                                                    \
         if (from_z)                                                                                                         \
             hipLaunchKernelGGL((hp_head_step_kernel<CPL, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,   \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega);                        \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext);                 \
         else                                                                                                                \
             hipLaunchKernelGGL((hp_head_step_kernel<CPL, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,  \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega);                        \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext);                 \
     } while (0)
     switch (hidden) {
         case 128: HP_HEAD_STEP(2); break;

@@ -43,10 +43,56 @@ def fourier_matrix(dim: int, mapping_size: int = 128, scale: float = 0.5, seed: 
     return (rng.normal(size=(mapping_size, dim)) * scale).astype(np.float32)
 
 
-def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512, hidden_layers: int = 3,
-               mapping_size: int = 128, ff_scale: float = 0.5, lr: float = 1e-4, seed: Optional[int] = 0,
-               downsample: bool = True, upscale_axes: int = 2, evaluate: bool = True, chunk_steps: int = 250,
-               return_recon: bool = True, normalize: bool = True, group=None) -> Dict[str, object]:
+FIT_OK, FIT_RESEEDED, FIT_FAILED, FIT_ERROR = 0, 1, 2, 3      # record["status"]: see fit_volume / run_volumes
+
+
+def fit_health(last_loss: float, recon: Optional[torch.Tensor] = None) -> str:
+    """The reference's only recovery logic, generalised: ``INR_ERD.py:211-217`` / ``prepare_qual_images.py:176-182`` re-create
+    the network when its whole output is zero (``if not model_output...max()``: a dead fit).  Here a fit is unhealthy when its
+    loss is not finite ("nan": full-batch Adam can diverge) or when the clamped reconstruction is zero everywhere or not finite
+    ("collapsed").  Returns "ok", "nan" or "collapsed"."""
+    if last_loss is not None and not np.isfinite(last_loss):
+        return "nan"
+    if recon is not None and recon.numel():
+        top = float(recon.max())
+        if not np.isfinite(top) or not bool(torch.isfinite(recon).all()):
+            return "nan"
+        if top <= 0.0:
+            return "collapsed"
+    return "ok"
+
+
+def fit_volume(volume: np.ndarray, steps: int = 2500, *args, seed: Optional[int] = 0, max_reseeds: int = 1, group=None,
+               _fault=None, **kwargs) -> Dict[str, object]:
+    """``_fit_volume_once`` (the fit itself: arguments there) under the reference's failure rule (``fit_health``): a fit whose
+    loss went non-finite or whose reconstruction collapsed to zero is run again from another seed (``seed + 7919 * attempt``: new
+    Fourier matrix and new weights, as the reference re-creates its network), at most ``max_reseeds`` times.  The result carries
+    ``status`` (FIT_OK, FIT_RESEEDED = healthy after a re-seed, FIT_FAILED = still unhealthy), ``health`` and ``reseeds``.
+    A fit shared by a rank group re-seeds on the loss only (every member sees the same all-reduced loss and must take the same
+    decision; the reconstruction exists on the group's first rank alone).  ``_fault(attempt)``: test hook (returns "nan" to
+    poison that attempt's targets)."""
+    attempt = 0
+    while True:
+        s = None if seed is None else seed + 7919 * attempt
+        res = _fit_volume_once(volume, steps, *args, seed=s, group=group,
+                               _poison=bool(_fault and _fault(attempt) == "nan"), **kwargs)
+        shared = group is not None and torch.distributed.get_world_size(group) > 1
+        health = fit_health(res.get("final_loss"), None if shared else res.get("_recon_probe"))
+        res.pop("_recon_probe", None)
+        res["health"], res["reseeds"] = health, attempt
+        if health == "ok":
+            res["status"] = FIT_RESEEDED if attempt else FIT_OK
+            return res
+        if attempt >= max_reseeds:
+            res["status"] = FIT_FAILED
+            return res
+        attempt += 1
+
+
+def _fit_volume_once(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512, hidden_layers: int = 3,
+                     mapping_size: int = 128, ff_scale: float = 0.5, lr: float = 1e-4, seed: Optional[int] = 0,
+                     downsample: bool = True, upscale_axes: int = 2, evaluate: bool = True, chunk_steps: int = 250,
+                     return_recon: bool = True, normalize: bool = True, group=None, _poison: bool = False) -> Dict[str, object]:
     """One INR super-resolution fit of an N-D volume (first ``upscale_axes`` axes are in-plane).
 
     ``downsample=True``: the volume is the HR ground truth, training uses ``vol[::2, ::2, ...]`` and the result is
@@ -79,6 +125,8 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
     data = ImageFitting_set([lr_vol])
     model_input = input_mapping(data.coords[0], B)                        # built once per fit (superresDWI.py:122)
     pixels = data.pixels[0]
+    if _poison:
+        pixels = pixels * float("nan")
     g_size = torch.distributed.get_world_size(group) if group is not None else 1
     g_rank = torch.distributed.get_rank(group) if group is not None else 0
     torch.cuda.synchronize()
@@ -96,6 +144,8 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
         k = min(chunk_steps, steps - done)
         losses.append(fitter.step(model_input, pixels, k))
         done += k
+        if not bool(torch.isfinite(losses[-1][-1])):     # diverged: the remaining steps cannot bring it back (fit_volume re-seeds)
+            break
     torch.cuda.synchronize()
     t_fit = time.perf_counter() - t0
     fitter.release_workspace()
@@ -126,6 +176,7 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, hidden_features: int = 512
             out["ssim_mean"] = float(vals.mean())
     if return_recon:
         out["recon"] = recon
+    out["_recon_probe"] = recon          # (fit_volume's health check; dropped there)
     out["model"] = model
     out["B"] = B
     return out
@@ -235,7 +286,8 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
             "train_voxels_per_s": total_steps * n_acq * side * side / dt, "model": model}
 
 
-RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss")
+RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss", "status", "reseeds", "rank",
+               "requeued")
 
 
 def hybrid_te_groups(world_size: int) -> List[List[int]]:
@@ -355,36 +407,80 @@ def plan_volumes(volumes: Sequence[np.ndarray], steps: int, world: int, allow_sh
 
 
 def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True, stats: Optional[dict] = None,
-                **fit_kwargs) -> List[Dict[str, float]]:
+                fit_fn=None, requeue: bool = True, **fit_kwargs) -> List[Dict[str, float]]:
     """Fits every volume once over the ranks of the current process group and returns the gathered per-fit metric
     records on every rank (one RCCL all_gather).  Schedule: ``plan_volumes`` / ``dist.plan_fits`` -- the volumes that do not
     fill a whole round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
     ``allow_sharding=False`` is plain LPT packing (no collective on the data path at all).  ``stats`` (a dict) receives the
-    plan and this rank's busy seconds."""
+    plan and this rank's busy seconds.
+
+    Failure handling (the job list is idempotent -- one record per fit).  Every record carries ``status``:
+    FIT_OK, FIT_RESEEDED (the fit diverged or collapsed and a re-seeded run was healthy: ``fit_volume``), FIT_FAILED (unhealthy
+    after the re-seeds: kept, marked, metrics as measured) or FIT_ERROR (the fit RAISED on its rank -- a device error, an
+    allocation failure).  With ``requeue`` the whole-volume fits that ended in FIT_ERROR are dealt, longest first, to the ranks
+    that reported no error (the survivors; every rank derives the same assignment from the gathered records), run there and
+    gathered once more; ``requeued`` = 1 marks their records.  A fit shared by a rank group is not re-queued: a member that
+    raises mid-fit leaves its partners in the gradient all-reduce, which this layer cannot repair -- the exception propagates.
+    ``fit_fn(volume, steps=..., return_recon=False, **fit_kwargs)`` replaces ``fit_volume`` (tests of the scheduling itself)."""
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    fit = fit_fn or fit_volume
     plan = plan_volumes(volumes, steps, world, allow_sharding, **fit_kwargs)
     local = []
     t_start = time.perf_counter()
+    nan = float("nan")
 
-    def record(job, res):
+    def record(job, res, requeued=0.0):
         local.append({"job": job, "n_coords": res["n_coords"], "steps": steps, "t_fit": res["t_fit"],
-                      "t_recon": res["t_recon"], "psnr_db": res.get("psnr_db", float("nan")),
-                      "ssim_mean": res.get("ssim_mean", float("nan")), "final_loss": res["final_loss"]})
+                      "t_recon": res["t_recon"], "psnr_db": res.get("psnr_db", nan),
+                      "ssim_mean": res.get("ssim_mean", nan),
+                      "final_loss": nan if res.get("final_loss") is None else res["final_loss"],
+                      "status": float(res.get("status", FIT_OK)), "reseeds": float(res.get("reseeds", 0)), "rank": float(rank),
+                      "requeued": requeued})
+
+    def run_whole(job, requeued=0.0):
+        try:
+            record(job, fit(volumes[job], steps=steps, return_recon=False, **fit_kwargs), requeued)
+        except Exception as e:  # noqa: BLE001 -- the record says so; the survivors take the job over
+            import sys
+            print(f"[run_volumes] rank {rank}: fit of volume {job} raised {type(e).__name__}: {e}", file=sys.stderr)
+            record(job, {"n_coords": float(np.asarray(volumes[job]).size), "t_fit": nan, "t_recon": nan, "final_loss": nan,
+                         "status": FIT_ERROR}, requeued)
 
     # gang phase: every rank creates every group (new_group is collective over the default group), then works in its own
     groups = [(job, ranks, inr_dist.rank_group(ranks)) for job, ranks in plan["gangs"]]
     for job, ranks, grp in groups:
         if rank in ranks:
-            res = fit_volume(volumes[job], steps=steps, return_recon=False, group=grp, **fit_kwargs)
+            res = fit(volumes[job], steps=steps, return_recon=False, group=grp, **fit_kwargs)
             if not res.get("partner"):
                 record(job, res)
     for job in plan["whole"][rank]:
-        record(job, fit_volume(volumes[job], steps=steps, return_recon=False, **fit_kwargs))
+        run_whole(job)
     if stats is not None:
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         stats["busy_s"] = time.perf_counter() - t_start
         stats["plan"] = plan
     max_jobs = max((len(p) for p in plan["whole"]), default=0) + 1
     records = inr_dist.gather_job_records(local, RECORD_KEYS, max_jobs)
+    failed = sorted((r for r in records if r["status"] == FIT_ERROR), key=lambda r: (-r["n_coords"], r["job"]))
+    if requeue and failed:
+        bad_ranks = {int(r["rank"]) for r in failed}
+        survivors = [k for k in range(world) if k not in bad_ranks]
+        if survivors:
+            busy = {k: sum(r["t_fit"] for r in records if int(r["rank"]) == k and r["t_fit"] == r["t_fit"]) for k in survivors}
+            mine = []
+            for r in failed:                               # longest first, each to the survivor that is free first
+                k = min(survivors, key=lambda q: (busy[q], q))
+                busy[k] += r["n_coords"] * steps * 1e-9
+                if k == rank:
+                    mine.append(int(r["job"]))
+            local.clear()
+            for job in mine:
+                run_whole(job, requeued=1.0)
+            second = inr_dist.gather_job_records(local, RECORD_KEYS, len(failed))
+            redone = {int(r["job"]): r for r in second}
+            records = [redone.get(int(r["job"]), r) if r["status"] == FIT_ERROR else r for r in records]
+            if stats is not None:
+                stats["requeued"] = sorted(redone)
     return sorted(records, key=lambda r: r["job"])

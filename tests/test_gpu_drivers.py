@@ -127,3 +127,18 @@ def test_fit_hybrid_flow_small():
     idx = np.arange(0, signals.shape[0], 13)
     ref = np.array([PO.trf_fit(s) for s in signals[idx]])
     PC.check_against(x[idx], ref)
+
+
+def test_fit_volume_reseeds_a_fit_whose_loss_went_nan(golden):
+    """SURVEY section 5 (INR_ERD.py:211-217): a diverged / collapsed fit is re-created and run again.  The first attempt's
+    targets are poisoned with NaN (test hook); it stops at its first chunk, the re-seeded attempt is an ordinary fit."""
+    hr = golden("pat07_slice11.npz")["hr"]
+    res = drivers.fit_volume(hr, steps=40, seed=0, chunk_steps=10, _fault=lambda attempt: "nan" if attempt == 0 else None)
+    assert (res["status"], res["reseeds"], res["health"]) == (drivers.FIT_RESEEDED, 1, "ok")
+    assert np.isfinite(res["final_loss"]) and np.isfinite(res["psnr_db"]) and float(res["recon"].max()) > 0
+    same = drivers.fit_volume(hr, steps=40, seed=7919, chunk_steps=10)          # the seed the second attempt used
+    assert same["status"] == drivers.FIT_OK and same["final_loss"] == res["final_loss"]
+    bad = drivers.fit_volume(hr, steps=40, seed=0, chunk_steps=10, max_reseeds=0, _fault=lambda attempt: "nan")
+    assert bad["status"] == drivers.FIT_FAILED and bad["health"] == "nan" and bad["t_fit"] < same["t_fit"] * 2
+    recs = drivers.run_volumes([hr, hr], steps=20, chunk_steps=10)
+    assert [r["status"] for r in recs] == [drivers.FIT_OK] * 2 and all(r["requeued"] == 0.0 for r in recs)
