@@ -287,6 +287,49 @@ def rams_leg(reps=3):
     return out
 
 
+def compat_loop_leg(x, target, steps=20, warmup=3):
+    """The reference's loop UNMODIFIED (superresDWI.py:132-138: `INR(x)` -> `((out - gt)**2).mean()` -> `zero_grad()` ->
+    `loss.backward()` -> `torch.optim.Adam.step()`) on the 128^3 workload: what a user who only swaps the import line gets.
+    `Siren.forward` under autograd runs the fused fit's kernels (inr_siren_forward_train / inr_siren_backward_train); the loss and
+    Adam are torch's own ATen kernels.  `layer_by_layer_ms_per_step`: the same loop with `inr.HP_AUTOGRAD = False` (one autograd
+    Function over the stand-alone exact-fp32 layer entry points: what this loop ran on through round 3)."""
+    import mri_super_resolution_amd as inr
+    from mri_super_resolution_amd import inr as inr_mod
+
+    def run(hp, k):
+        inr_mod.HP_AUTOGRAD = hp
+        try:
+            torch.manual_seed(0)
+            INR = inr.Siren(IN_F, HIDDEN, LAYERS, OUT_F).cuda()
+            inr_optim = torch.optim.Adam(lr=1e-4, params=INR.parameters())
+            loss = None
+            for ctr in range(warmup + k):
+                if ctr == warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                model_output = INR(x)
+                loss = ((model_output - target) ** 2).mean()
+                inr_optim.zero_grad()
+                loss.backward()
+                inr_optim.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / k
+            final = float(loss)
+            del INR, inr_optim, model_output, loss
+            torch.cuda.empty_cache()
+            return dt, final
+        finally:
+            inr_mod.HP_AUTOGRAD = True
+
+    dt, final = run(True, steps)
+    dt_old, _ = run(False, max(5, steps // 2))
+    n = x.shape[0]
+    return {"config": "superresDWI.py:132-138 verbatim through compat/SRDWI's Siren: torch autograd + torch.optim.Adam around "
+                      "inr_siren_forward_train / inr_siren_backward_train, synthetic 128^3 workload",
+            "ms_per_step": dt * 1e3, "voxels_per_s": n / dt, "steps": steps, "final_loss": final,
+            "layer_by_layer_ms_per_step": dt_old * 1e3}
+
+
 def small_net_leg(steps=2000, side=60, n_acq=4):
     """The master.py regime (a-11): Siren(2,64,6,1) on a 60x60 slice, weighted loss, the acquisition changing every step:
     microseconds per optimizer step through one inr_siren_fit_cycle call (persistent kernel, 64 steps per launch)."""
@@ -608,6 +651,8 @@ def main():
                                "e2e_voxels_per_s": n_test / (t_fit + t_inf), "final_loss": float(full_losses[-1]),
                                "power_during_fit": telemetry or None}
             del rec, net_full
+        out["compat_loop"] = compat_loop_leg(x, target, steps=max(5, min(args.steps, 20)))
+        out["compat_loop"]["vs_fused_step"] = out["compat_loop"]["ms_per_step"] / out["ms_per_step"]
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
         out["small_net"] = small_net_leg()

@@ -114,6 +114,11 @@ SIGNATURES = {
                                       c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "inr_siren_loss_grad_ex": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int64,
                                          c_f32p, C.c_void_p, C.c_size_t, C.c_int, c_stream]),
+    "inr_siren_hp_eligible": (C.c_int, [C.POINTER(SirenDesc)]),
+    "inr_siren_forward_train": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_size_t, C.c_int,
+                                          c_stream]),
+    "inr_siren_backward_train": (C.c_int, [C.POINTER(SirenDesc), c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_size_t,
+                                           c_stream]),
     "inr_rams_shift_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "inr_rams_shift_loss": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, c_stream]),

@@ -120,6 +120,9 @@ class ImageFitting_set(torch.utils.data.Dataset):
 # ---------------------------------------------------------------------------------------------------
 # a-4 / a-5  SineLayer, Siren
 # ---------------------------------------------------------------------------------------------------
+HP_AUTOGRAD = True      # Siren.forward under autograd: the fused fit's kernels where they serve the shape (_SirenHpFn)
+
+
 class _SineLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, omega):
@@ -215,6 +218,85 @@ class _SirenFn(torch.autograd.Function):
         return (gx, None, None, *grads)
 
 
+class _TrainState:
+    """What the autograd path on the fused fit's kernels keeps per model (``_SirenHpFn``): the flat parameter buffer the module's
+    parameters are views of (network order, as ``inr_siren_param_offsets`` lays it out -- the kernels prepare all weight images
+    from it in two launches) and a stash workspace that is handed from the forward to its backward."""
+
+    def __init__(self, model):
+        self.model = model
+        self.desc = model.desc()
+        self.total, self.offsets = ops.siren_param_layout(self.desc)
+        self.flat = None
+        self._views = []
+        self._free_ws = None          # a workspace no pending forward owns
+        self._last = None             # (workspace data_ptr, x data_ptr, x._version, n) of the last forward: operand image reuse
+
+    def ensure(self):
+        params = self.model.layer_parameters()
+        if self.flat is not None and self.flat.device == params[0].device and \
+                all(p.data_ptr() == v.data_ptr() for p, v in zip(params, self._views)):
+            return
+        flat = torch.zeros(self.total, dtype=torch.float32, device=params[0].device)
+        views = []
+        for l, (w_off, b_off) in enumerate(self.offsets):
+            w, b = params[2 * l], params[2 * l + 1]
+            vw = flat[w_off:w_off + w.numel()].view_as(w)
+            vb = flat[b_off:b_off + b.numel()].view_as(b)
+            vw.copy_(w.detach())
+            vb.copy_(b.detach())
+            w.data, b.data = vw, vb
+            views += [vw, vb]
+        self.flat, self._views, self._last = flat, views, None
+
+    def take_workspace(self, n, device):
+        need = ops.siren_fit_workspace_bytes(self.desc, n)
+        ws, self._free_ws = self._free_ws, None
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
+
+    def give_back(self, ws):
+        if self._free_ws is None or ws.numel() >= self._free_ws.numel():
+            self._free_ws = ws
+
+    def split_grads(self, flat_grads):
+        out = []
+        for l, (w_off, b_off) in enumerate(self.offsets):
+            w, b = self._views[2 * l], self._views[2 * l + 1]
+            out += [flat_grads[w_off:w_off + w.numel()].view_as(w), flat_grads[b_off:b_off + b.numel()].view_as(b)]
+        return out
+
+
+class _SirenHpFn(torch.autograd.Function):
+    """The reference's own loop -- ``out = INR(x)``, torch forms the loss, ``loss.backward()``, ``torch.optim.Adam.step()``
+    (superresDWI.py:132-138) -- on the kernels of the fused fit: ONE call enqueues the weight preparation and the forward of every
+    layer with its stash (``inr_siren_forward_train``), one call the whole backward pass and the fixed-order gradient reduction
+    (``inr_siren_backward_train``).  ``_SirenFn`` below, the layer-by-layer form on the exact-fp32 kernels, remains for the shapes
+    these kernels do not serve and for inputs that want their own gradient."""
+
+    @staticmethod
+    def forward(ctx, x, state, *params):
+        x = x.contiguous()
+        n = x.shape[0]
+        ws = state.take_workspace(n, x.device)
+        key = (ws.data_ptr(), x.data_ptr(), x._version, n)
+        flags = ops.REUSE_INPUT_IMAGE if state._last == key else 0
+        y, ws = ops.siren_forward_train(state.desc, state.flat, x, ws, flags)
+        state._last = key
+        ctx.state, ctx.ws, ctx.x = state, ws, x          # (x kept alive: the backward's layer-0 GEMM reads its operand image only,
+        return y                                         #  but the C side remembers the pointer)
+
+    @staticmethod
+    def backward(ctx, gy):
+        st = ctx.state
+        grads = torch.empty(st.total, dtype=torch.float32, device=gy.device)      # fresh: .grad may alias what is returned here
+        ops.siren_backward_train(st.desc, st.flat, grads, gy.contiguous(), ctx.ws)
+        st.give_back(ctx.ws)
+        ctx.ws = None
+        return (None, None, *st.split_grads(grads))
+
+
 class Siren(nn.Module):
     """``Siren(in_features, hidden_features, hidden_layers, out_features, first_omega_0=30.,
     hidden_omega_0=30.)`` -- SRDWI.py:67-91 (``flavor='SRDWI'``, also nn_mri.py:122-146) or
@@ -273,10 +355,30 @@ class Siren(nn.Module):
         if self.flavor == "SRDWI":
             coords = coords.detach()  # SRDWI.py:88 (the reference also clones; the kernels never write x)
         lead = coords.shape[:-1]
-        y = _SirenFn.apply(coords.reshape(-1, coords.shape[-1]), self.first_omega_0, self.hidden_omega_0,
-                           *self.layer_parameters())
+        flat_x = coords.reshape(-1, coords.shape[-1])
+        params = self.layer_parameters()
+        if self._hp_train_ok(flat_x, params):
+            st = self.__dict__.get("_hp_state")
+            if st is None:
+                st = self.__dict__["_hp_state"] = _TrainState(self)
+            st.ensure()
+            y = _SirenHpFn.apply(flat_x, st, *self.layer_parameters())
+        else:
+            y = _SirenFn.apply(flat_x, self.first_omega_0, self.hidden_omega_0, *params)
         y = y.reshape(*lead, self.out_features)
         return (y, coords) if self.return_coords else y
+
+    def _hp_train_ok(self, x, params) -> bool:
+        """The fused kernels take a training forward when every parameter wants a gradient, the input does not, everything is
+        fp32 on the device and the shape is one they serve; ``inr.HP_AUTOGRAD = False`` keeps the layer-by-layer path (A/B)."""
+        if not (HP_AUTOGRAD and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad):
+            return False
+        if not all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in params):
+            return False
+        ok = self.__dict__.get("_hp_ok")
+        if ok is None:
+            ok = self.__dict__["_hp_ok"] = ops.siren_hp_eligible(self.desc())
+        return ok
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -464,6 +464,44 @@ def siren_loss_grad(desc: SirenDesc, params, grads, x, target, weight, count_tot
     return workspace
 
 
+def siren_hp_eligible(desc: SirenDesc) -> bool:
+    """May the whole-network entry points run this shape on the pre-split kernels (``inr_siren_forward_train`` needs it)?"""
+    return bool(lib().inr_siren_hp_eligible(C.byref(desc)))
+
+
+def siren_forward_train(desc: SirenDesc, params, x, workspace=None, flags: int = 0):
+    """``inr_siren_forward_train``: y = network(x), every layer's stash left in ``workspace`` for ``siren_backward_train``.
+    Returns (y [n, 1], workspace)."""
+    total, _ = siren_param_layout(desc)
+    _chk(params, "params")
+    _chk(x, "x")
+    if params.numel() != total or x.dim() != 2 or x.shape[1] != desc.in_features:
+        raise ValueError("params / x shape mismatch")
+    n = x.shape[0]
+    need = siren_fit_workspace_bytes(desc, n)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        if flags:
+            raise ValueError("REUSE_* flags need the workspace of the previous call")
+        workspace = _ws(need, x.device)
+    y = torch.empty(n, desc.out_features, dtype=torch.float32, device=x.device)
+    check(lib().inr_siren_forward_train(C.byref(desc), params.data_ptr(), x.data_ptr(), y.data_ptr(), n, workspace.data_ptr(),
+                                        workspace.numel() * workspace.element_size(), int(flags), _stream()),
+          "inr_siren_forward_train")
+    return y, workspace
+
+
+def siren_backward_train(desc: SirenDesc, params, grads, gy, workspace):
+    """``inr_siren_backward_train``: the flat gradient (network order) of sum(gy * y) from the pending forward's stash."""
+    _chk(params, "params")
+    _chk(grads, "grads")
+    _chk(gy, "gy")
+    n = gy.numel() // desc.out_features
+    check(lib().inr_siren_backward_train(C.byref(desc), params.data_ptr(), grads.data_ptr(), gy.data_ptr(), n,
+                                         workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()),
+          "inr_siren_backward_train")
+    return grads
+
+
 # ---- diagnostics ------------------------------------------------------------------------------------------
 LAUNCH_FAMILIES = ("hp_pkd", "hp_pkc", "hp_tile", "hp_rc", "h3", "f32_pipe16", "f32_pipe", "f32_generic", "small_multi",
                    "small_step", "hp_narrow", "hp_fused_fwd")   # INR_LF_* of include/inrhip.h, in order

@@ -1,0 +1,180 @@
+"""-m gpu: the reference's OWN loop (superresDWI.py:132-138: ``INR(x)`` -> torch forms the loss -> ``loss.backward()`` ->
+``torch.optim.Adam.step()``) on the fused fit's kernels (``_SirenHpFn``: inr_siren_forward_train / inr_siren_backward_train)
+against the reference fixtures, the torch-CPU port and the layer-by-layer exact-fp32 path it replaces."""
+import numpy as np
+import pytest
+import torch
+
+import mri_super_resolution_amd as inr
+from mri_super_resolution_amd import inr as inr_mod
+from mri_super_resolution_amd import ops
+from oracle import inr_oracle as O
+from oracle import torch_port as P
+from tests.conftest import strided_sample
+
+pytestmark = pytest.mark.gpu
+T1 = T2 = 1e-5
+T3 = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture
+def legacy_autograd():
+    inr_mod.HP_AUTOGRAD = False
+    yield
+    inr_mod.HP_AUTOGRAD = True
+
+
+def _net(golden, flavor="SRDWI"):
+    d = golden("dataset_ff.npz")
+    torch.manual_seed(0)
+    net = inr.Siren(256, 512, 3, 1, flavor=flavor).cuda()
+    x = inr.input_mapping(inr.get_mgrid((64, 64)), dev(d["B2"]))
+    return net, x, d
+
+
+def test_which_kernels_each_mode_runs(golden):
+    net, x, d = _net(golden)
+    t = dev(d["lr_pixels"][0])
+    ops.launch_counts_reset()
+    ((net(x) - t) ** 2).mean().backward()
+    c = ops.launch_counts()
+    assert c["hp_narrow"] + c["hp_pkd"] + c["hp_pkc"] + c["hp_tile"] >= 7 and c["hp_rc"] == 4 and c["f32_pipe16"] == 0, c
+    inr_mod.HP_AUTOGRAD = False
+    try:
+        net.zero_grad()
+        ops.launch_counts_reset()
+        ((net(x) - t) ** 2).mean().backward()
+        c = ops.launch_counts()
+        assert c["f32_pipe16"] >= 11 and c["hp_rc"] == 0, c
+    finally:
+        inr_mod.HP_AUTOGRAD = True
+    with torch.no_grad():                                   # inference under no_grad never takes the stash path
+        ops.launch_counts_reset()
+        net(x)
+        assert ops.launch_counts()["hp_rc"] == 0
+
+
+@pytest.mark.parametrize("flavor", ["SRDWI", "INRmodel"])
+def test_forward_and_gradients_match_reference(golden, flavor):
+    g = golden("siren512_step0.npz")
+    net, x, d = _net(golden, flavor)
+    t = dev(d["lr_pixels"][0])
+    out = net(x)
+    assert O.rel_l2(host(out), g[f"{flavor}/fwd"]) < T1
+    loss = ((out - t) ** 2).mean()
+    loss.backward()
+    if flavor == "SRDWI":
+        assert abs(loss.item() - g["SRDWI/loss0"]) / g["SRDWI/loss0"] < T2
+        for n, p in net.named_parameters():
+            gr = host(p.grad)
+            assert O.rel_l2(strided_sample(gr), g[f"SRDWI/grad_strided/{n}"]) < T2, n
+            nrm = np.linalg.norm(gr.astype(np.float64))
+            assert abs(nrm - g[f"SRDWI/grad_norm/{n}"]) / g[f"SRDWI/grad_norm/{n}"] < T2, n
+    torch.manual_seed(0)
+    ref = P.PortSiren(256, 512, 3, 1, flavor=flavor)
+    ((ref(torch.from_numpy(host(x))) - torch.from_numpy(d["lr_pixels"][0])) ** 2).mean().backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert O.rel_l2(host(p.grad), q.grad.numpy()) < T2, n
+
+
+def test_arbitrary_upstream_gradient_and_weighted_loss_vs_float64(golden):
+    """dL/dy is whatever autograd hands over (here a weighted, cubed residual): every gradient tensor against float64."""
+    net, x, d = _net(golden)
+    t = dev(d["lr_pixels"][0])
+    w = dev(np.random.default_rng(3).random((4096, 1)) + 0.1)
+    (w * (net(x) - t).abs() ** 3).sum().backward()
+    torch.manual_seed(0)
+    ref = P.PortSiren(256, 512, 3, 1).double()
+    (torch.from_numpy(host(w)).double() * (ref(torch.from_numpy(host(x)).double()) - torch.from_numpy(d["lr_pixels"][0]).double()).abs() ** 3
+     ).sum().backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert O.rel_l2(host(p.grad), q.grad.numpy()) < T2, n
+
+
+def test_matches_the_layer_by_layer_path_and_the_fused_fit(golden):
+    net, x, d = _net(golden)
+    t = dev(d["lr_pixels"][0])
+    ((net(x) - t) ** 2).mean().backward()
+    hp = {n: host(p.grad).copy() for n, p in net.named_parameters()}
+    net.zero_grad()
+    inr_mod.HP_AUTOGRAD = False
+    try:
+        ((net(x) - t) ** 2).mean().backward()
+    finally:
+        inr_mod.HP_AUTOGRAD = True
+    for n, p in net.named_parameters():
+        assert O.rel_l2(hp[n], host(p.grad)) < 3e-6, n
+    fitter = inr.SirenFitter(net, lr=0.0)
+    fitter.step(x, t, n_steps=1)
+    names = ["net.%d.linear.%s" % (l, k) for l in range(4) for k in ("weight", "bias")] + ["final_linear.weight", "final_linear.bias"]
+    for l, (w_off, b_off) in enumerate(fitter.offsets):
+        gw = host(fitter.grads[w_off:w_off + hp[names[2 * l]].size]).reshape(hp[names[2 * l]].shape)
+        assert O.rel_l2(gw, hp[names[2 * l]]) < 1e-6, names[2 * l]        # same kernels; only dL/dy is formed elsewhere
+
+
+def test_accumulation_pending_forwards_and_inplace_inputs(golden):
+    net, x, d = _net(golden)
+    t = dev(d["lr_pixels"][0])
+    ((net(x) - t) ** 2).mean().backward()
+    once = {n: p.grad.clone() for n, p in net.named_parameters()}
+    ((net(x) - t) ** 2).mean().backward()                                      # accumulates into .grad
+    for n, p in net.named_parameters():
+        assert torch.allclose(p.grad, 2 * once[n], rtol=1e-6, atol=0), n
+    net.zero_grad()
+    x2 = x.flip(0).contiguous()
+    y1, y2 = net(x), net(x2)                                                   # two forwards pending, backward through both
+    (((y1 - t) ** 2).mean() + ((y2 - t.flip(0)) ** 2).mean()).backward()
+    for n, p in net.named_parameters():
+        assert O.rel_l2(host(p.grad), host(2 * once[n])) < 2e-6, n
+    net.zero_grad()
+    xm = x.clone()
+    a = net(xm)
+    xm.mul_(0.5)                                                               # same storage, new contents: no operand-image reuse
+    b = net(xm)
+    with torch.no_grad():
+        want = net(x * 0.5)
+    assert O.rel_l2(host(b), host(want)) < 1e-6 and O.rel_l2(host(a), host(b)) > 1e-2
+    (b.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_reference_loop_verbatim_ten_steps(golden):
+    """superresDWI.py:132-138 as written, 10 steps, against the reference trajectory (T3) -- on both autograd paths."""
+    tr = golden("siren512_traj.npz")
+    for hp in (True, False):
+        inr_mod.HP_AUTOGRAD = hp
+        try:
+            INR, model_input, d = _net(golden)
+            ground_truth = dev(d["lr_pixels"][0])
+            inr_optim = torch.optim.Adam(lr=1e-4, params=INR.parameters())
+            for ctr in range(10):
+                model_output = INR(model_input)
+                loss = ((model_output - ground_truth) ** 2).mean()
+                inr_optim.zero_grad()
+                loss.backward()
+                inr_optim.step()
+            rec = host(inr.reconstruct(INR, (128, 128), dev(d["B2"])))
+            assert O.rel_l2(rec, tr["t8/recon_10"]) < T3, hp
+        finally:
+            inr_mod.HP_AUTOGRAD = True
+
+
+def test_small_and_ineligible_shapes_keep_working():
+    torch.manual_seed(1)
+    net = inr.Siren(2, 64, 6, 1).cuda()                                        # not served by the pre-split kernels' entry points?
+    x = torch.rand(300, 2, device="cuda") * 2 - 1
+    net(x).sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    torch.manual_seed(1)
+    ref = P.PortSiren(2, 64, 6, 1)
+    ref(x.cpu()).sum().backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert O.rel_l2(host(p.grad), q.grad.numpy()) < 5e-5, n
