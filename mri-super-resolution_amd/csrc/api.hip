@@ -81,11 +81,13 @@ int gemm_build_flags();
 size_t hp_prep_part_bytes();
 int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* slots,
                    unsigned* part, float* head_bound, const float* head_W, const float* head_b, int hidden, const unsigned* tmax,
-                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream);
+                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream, const float* const* bias = nullptr,
+                   const float* layer_omega = nullptr, float* act_bound = nullptr, const unsigned* x_amax = nullptr);
 int hp_convert(char* out, const float* x, long long rows, int cols, HpScale sc, hipStream_t stream);
 int hp_unconvert(float* out, const char* x, long long rows, int cols, HpScale sc, hipStream_t stream);
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
-                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false);
+                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only = false,
+                    HpScale so = HpScale{});
 bool hp_z_stash_ok(int in_f);
 bool hp_grid_fourier_ok(int m, int dim);
 int hp_grid_fourier_hl(char* x_hl, unsigned* x_amax, const int64_t* shape, int dim, int64_t row_begin, int64_t n_rows, const float* B,
@@ -107,11 +109,11 @@ int hp_param_grad_slabs(float* slabs, int splits, const char* dz_hl, const char*
 int hp_param_grad_multi_max();
 int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStream_t stream);
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
-                    float clamp_min, hipStream_t stream, bool from_z = false, float omega = 0.f);
+                    float clamp_min, hipStream_t stream, bool from_z = false, float omega = 0.f, HpScale sa = HpScale{});
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
                  int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z = false,
-                 float omega = 0.f, const float* g_ext = nullptr);
+                 float omega = 0.f, const float* g_ext = nullptr, HpScale sa = HpScale{});
 int hp_head_bound_ext(float* head_bound, const unsigned* gmax, const float* head_W, int hidden, float omega, hipStream_t stream);
 int gemm_param_grad_slabs(float* slabs, int splits, const float* dz, const float* x, int64_t n, int in_f,
                           int out_f, hipStream_t stream, const H3Args* h3 = nullptr);
@@ -372,7 +374,17 @@ struct HpNet {
     char* wT_hl(int l) const { return w_hl(l) + 4ll * L->fan_in[l] * L->fan_out[l]; }
     HpScale w_scale(int l) const { HpScale s; s.meas = c->slots + l; s.mul = 1.f; return s; }
     HpScale x_scale() const { HpScale s; s.meas = c->slots + 24; s.mul = 1.f; return s; }
-    HpScale act_scale(int l) const { return l == 0 ? x_scale() : HpScale{}; }   // input of sine layer l
+    // input of sine layer l: the network input (measured max|x|) or the output of layer l - 1, whose image is scaled from the
+    // a-priori bound of that layer (slots 32 + l - 1, written by the per-step weight preparation: gemm_hp.inc, act_bound)
+    HpScale act_scale(int l) const {
+        if (l == 0) return x_scale();
+        HpScale s;
+        s.wn = reinterpret_cast<const float*>(c->slots + 32 + l - 1);
+        s.mul = 1.f;
+        s.kmax = 40;
+        return s;
+    }
+    float* act_bounds() const { return reinterpret_cast<float*>(c->slots + 32); }
     float* head_bound() const { return reinterpret_cast<float*>(c->slots + 27); }
 };
 // this step's weights as HL32 images + their scales; with `head` (fit steps) also the a-priori bound of the head's dz
@@ -383,19 +395,27 @@ struct HpHeadBoundArgs {
     const unsigned* wtmax;
     float inv_count, omega;
 };
-static int hp_refresh_weights(const HpNet& net, const float* params, hipStream_t st, const HpHeadBoundArgs* head = nullptr) {
+// x_measured: slot 24 holds max|x| of the rows this step runs on (the fit / forward entry points measure it first); false:
+// the input is a coordinate grid or its Fourier features, |x| <= 1 (the dense re-sampling prepares the weights once per call,
+// before any chunk's input exists)
+static int hp_refresh_weights(const HpNet& net, const inr_siren_desc_t* d, const float* params, hipStream_t st, bool x_measured,
+                              const HpHeadBoundArgs* head = nullptr) {
     const Layout& L = *net.L;
-    const float* W[8];
+    const float *W[8], *bias[8];
+    float om[8];
     int of[8], inf[8];
     for (int l = 0; l < L.n_sine; ++l) {
         W[l] = params + L.w_off[l];
+        bias[l] = params + L.b_off[l];
+        om[l] = l == 0 ? d->first_omega : d->hidden_omega;
         of[l] = L.fan_out[l];
         inf[l] = L.fan_in[l];
     }
     return hp_weight_prep(W, of, inf, L.n_sine, reinterpret_cast<char*>(net.c->planes), net.c->slots, net.c->part,
                           head ? net.head_bound() : nullptr, head ? head->W : nullptr, head ? head->b : nullptr,
                           L.fan_in[L.n_sine], head ? head->tmax : nullptr, head ? head->wtmax : nullptr,
-                          head ? head->inv_count : 0.f, head ? head->omega : 0.f, st);
+                          head ? head->inv_count : 0.f, head ? head->omega : 0.f, st, bias, om, net.act_bounds(),
+                          x_measured ? net.c->slots + 24 : nullptr);
 }
 
 static size_t head_backward_ws_floats(int64_t n, int hidden, int out_f) {
@@ -623,11 +643,13 @@ size_t inr_siren_forward_workspace_bytes(const inr_siren_desc_t* desc, int64_t n
 
 static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const float* params, const float* x,
                               int64_t n, float* y, int use_clamp, float clamp_min, float* buf0, float* buf1,
-                              hipStream_t st, const H3Ctx* h3 = nullptr, char* xhl = nullptr, bool xhl_ready = false) {
+                              hipStream_t st, const H3Ctx* h3 = nullptr, char* xhl = nullptr, bool xhl_ready = false,
+                              bool amax_ready = false) {
     // xhl_ready: the caller has already written the HL32 image of the input and its scale slot (hp_grid_fourier_hl); x unused
+    // amax_ready: the caller has measured max|x| into slot 24 (inr_siren_forward: before the weight preparation, which needs it)
     const float* cur = x;
     float* bufs[2] = {buf0, buf1};
-    if (h3 && h3->on && !xhl_ready) {
+    if (h3 && h3->on && !xhl_ready && !amax_ready) {
         if (int rc = h3_tensor_amax(h3->slots + 24, x, (long long)n * L.fan_in[0], st, 0x3f800000u)) return rc;
     }
     if (h3 && h3->on && xhl) {   // pre-split path: every activation lives in HBM as HL32 (gemm_hp.inc)
@@ -654,12 +676,12 @@ static int siren_forward_impl(const inr_siren_desc_t* d, const Layout& L, const 
             char* dst = reinterpret_cast<char*>(bufs[l & 1]);
             const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
             if (int rc = hp_sine_forward(dst, nullptr, in, net.w_hl(l), params + L.b_off[l], n, L.fan_in[l], L.fan_out[l],
-                                         omega, net.act_scale(l), net.w_scale(l), 0, st))
+                                         omega, net.act_scale(l), net.w_scale(l), 0, st, false, net.act_scale(l + 1)))
                 return rc;
             in = dst;
         }
         return hp_head_forward(y, in, params + L.w_off[L.n_sine], params + L.b_off[L.n_sine], n, d->hidden_features,
-                               use_clamp, clamp_min, st);
+                               use_clamp, clamp_min, st, false, 0.f, net.act_scale(L.n_sine));
     }
     for (int l = 0; l < L.n_sine; ++l) {
         float* dst = bufs[l & 1];
@@ -688,18 +710,23 @@ int inr_siren_forward(const inr_siren_desc_t* desc, const float* params, const f
     const size_t half = round_up((size_t)n * desc->hidden_features * sizeof(float), 256);
     float* b0 = (float*)workspace;
     float* b1 = (float*)((char*)workspace + half);
+    bool amax_ready = false;
     H3Ctx h3;
     char* xhl = nullptr;
     if (h3_eligible(L)) {
         h3 = h3_make_ctx(L, (char*)workspace + 2 * half);
         if (hp_eligible(desc, L)) {
             xhl = (char*)workspace + 2 * half + h3_ctx_bytes(L);
-            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, params, (hipStream_t)stream)) return rc;
+            // max|x| first: the a-priori bounds of the layers' outputs (the scales of their images) start from it
+            if (int rc = h3_tensor_amax(h3.slots + 24, x, (long long)n * L.fan_in[0], (hipStream_t)stream, 0x3f800000u)) return rc;
+            amax_ready = true;
+            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, desc, params, (hipStream_t)stream, true)) return rc;
         } else if (int rc = h3_refresh_weights(h3, L, params, (hipStream_t)stream)) {
             return rc;
         }
     }
-    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream, &h3, xhl);
+    return siren_forward_impl(desc, L, params, x, n, y, use_clamp, clamp_min, b0, b1, (hipStream_t)stream, &h3, xhl, false,
+                              amax_ready);
 }
 
 size_t inr_siren_reconstruct_workspace_bytes(const inr_siren_desc_t* desc, int64_t chunk_rows) {
@@ -744,7 +771,7 @@ int inr_siren_reconstruct(const inr_siren_desc_t* desc, const float* params, con
         h3 = h3_make_ctx(L, (char*)workspace + feats_b + 2 * act_b);
         if (hp_eligible(desc, L)) {
             xhl = (char*)workspace + feats_b + 2 * act_b + h3_ctx_bytes(L);
-            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, params, st)) return rc;
+            if (int rc = hp_refresh_weights(HpNet{&h3, &L}, desc, params, st, false)) return rc;
         } else if (int rc = h3_refresh_weights(h3, L, params, st)) {
             return rc;
         }
@@ -930,7 +957,7 @@ static int hp_forward_pass(const inr_siren_desc_t* d, const Layout& L, const flo
         const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
         if (int rc = hp_sine_forward(reinterpret_cast<char*>(act[l + 1]), dact[l], act_hl(l), net.w_hl(l), params + L.b_off[l], n,
                                      L.fan_in[l], L.fan_out[l], omega, net.act_scale(l), net.w_scale(l), 0, st,
-                                     z_head && l == head - 1))
+                                     z_head && l == head - 1, net.act_scale(l + 1)))
             return rc;
     }
     return 0;
@@ -982,7 +1009,8 @@ static int hp_backward_pass(const inr_siren_desc_t* d, const Layout& L, const fl
         if (int rc = hp_head_step(reinterpret_cast<char*>(dact[head - 1]), const_cast<float*>(fin.seg[kb].slab),
                                   const_cast<float*>(fin.seg[kw].slab), part_loss, const_cast<float*>(fin.seg[kg].slab),
                                   act_hl(head), dact[head - 1], params + L.w_off[head], params + L.b_off[head], target, weight,
-                                  n, H, count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last, g_ext))
+                                  n, H, count_total, ctx.slots + 8 + head - 1, dz_scale(head - 1), st, z_head, omega_last, g_ext,
+                                  net.act_scale(head)))
             return rc;
         fin.seg[kb].nslabs = fin.seg[kw].nslabs = fin.seg[kg].nslabs = blocks;
         fin.part_loss = part_loss;
@@ -1039,7 +1067,7 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
     const float omega_last = (head - 1 == 0) ? d->first_omega : d->hidden_omega;
     const HpHeadBoundArgs hb{params + L.w_off[head], params + L.b_off[head], ctx.slots + 25, weight ? ctx.slots + 26 : nullptr,
                              inv, omega_last};
-    if (int rc = hp_refresh_weights(net, params, st, &hb)) return rc;
+    if (int rc = hp_refresh_weights(net, d, params, st, true, &hb)) return rc;
     // the output of the LAST sine layer feeds nothing but the head: that layer stashes z + b only (one fp32 matrix instead
     // of act + omega cos) and the head step forms sin / cos itself -- 2.1 GB less HBM traffic per step at N = 524,288
     const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
@@ -1345,13 +1373,14 @@ int inr_siren_forward_train(const inr_siren_desc_t* desc, const float* params, c
         if (int rc = hp_convert(t.xhl, x, n, L.fan_in[0], sx, st)) return rc;
     }
     const HpNet net{&t.h3, &L};
-    if (int rc = hp_refresh_weights(net, params, st, nullptr)) return rc;      // (also zeroes this step's dz maxima)
+    if (int rc = hp_refresh_weights(net, desc, params, st, true, nullptr)) return rc;      // (also zeroes this step's dz maxima)
     const int head = L.n_sine;
     const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
     if (int rc = hp_forward_pass(desc, L, params, t.act, t.dact, t.xhl, n, st, t.h3, z_head)) return rc;
     const float omega_last = (head - 1 == 0) ? desc->first_omega : desc->hidden_omega;
     return hp_head_forward(y, z_head ? reinterpret_cast<const char*>(t.dact[head - 1]) : reinterpret_cast<const char*>(t.act[head]),
-                           params + L.w_off[head], params + L.b_off[head], n, desc->hidden_features, 0, 0.f, st, z_head, omega_last);
+                           params + L.w_off[head], params + L.b_off[head], n, desc->hidden_features, 0, 0.f, st, z_head, omega_last,
+                           net.act_scale(head));
 }
 
 int inr_siren_backward_train(const inr_siren_desc_t* desc, const float* params, float* grads, const float* gy, int64_t n,

@@ -62,7 +62,9 @@ struct H3Args {
 struct HpScale {
     const unsigned* meas = nullptr;   // float bits (an atomic-max slot of a FINISHED kernel), nullable
     const float* wn = nullptr;        // device float, nullable
-    float mul = 0.f;                  // 0 = no scale at all (tensor in [-1, 1]: sine outputs)
+    float mul = 0.f;                  // 0 = no scale at all
+    int kmax = 126;                   // largest exponent of the scale (bounds with `wn`: gradients use the whole range; sine outputs
+                                      // stop at 40 so that the folded bias b 2^(ka + kb) stays finite)
 };
 
 // one parameter-gradient GEMM of a step (hp_param_grad_multi: all of them in one launch)

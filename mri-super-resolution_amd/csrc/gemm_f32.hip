@@ -1121,14 +1121,16 @@ bool hp_head_ok(int hidden) { return hidden == 128 || hidden == 256 || hidden ==
 size_t hp_prep_part_bytes() { return (size_t)8 * HP_PREP_MAXB * 2 * sizeof(unsigned); }
 int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* slots,
                    unsigned* part, float* head_bound, const float* head_W, const float* head_b, int hidden, const unsigned* tmax,
-                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream) {
+                   const unsigned* wtmax, float inv_count, float omega, hipStream_t stream, const float* const* bias,
+                   const float* layer_omega, float* act_bound, const unsigned* x_amax) {
     INR_REQUIRE(layers >= 1 && layers <= 8, INR_E_INVALID, "hp_weight_prep: %d layers", layers);
     HpWeightJobs jobs{};
     char* cur = planes;
     int max_tiles = 1, max_sb = 1;
     for (int l = 0; l < layers; ++l) {
         const long long n = (long long)out_f[l] * in_f[l];
-        jobs.job[l] = HpWeightJob{W[l], cur, cur + 4 * n, slots + l, slots + 16 + l, out_f[l], in_f[l]};
+        jobs.job[l] = HpWeightJob{W[l], cur, cur + 4 * n, slots + l, slots + 16 + l, out_f[l], in_f[l], bias ? bias[l] : nullptr,
+                                  layer_omega ? layer_omega[l] : 0.f};
         cur += 8 * n;
         const int t = ((out_f[l] + 63) / 64) * ((in_f[l] + 63) / 64);
         if (t > max_tiles) max_tiles = t;
@@ -1141,6 +1143,7 @@ int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int
     jobs.head_bound = head_bound;
     jobs.head_W = head_W; jobs.head_b = head_b; jobs.hidden = hidden;
     jobs.tmax = tmax; jobs.wtmax = wtmax; jobs.inv_count = inv_count; jobs.omega = omega;
+    jobs.act_bound = act_bound; jobs.x_amax = x_amax;
     ProfScope ps(KC_OTHER, stream);
     hipLaunchKernelGGL(hp_weight_stats_kernel, dim3(max_sb, layers), dim3(256), 0, stream, jobs);
     INR_LAUNCH_CHECK();
@@ -1223,13 +1226,13 @@ static int hp_launch_narrow(HpParams p, int64_t row0, int64_t rows, bool xzy, hi
 }
 
 int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f,
-                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only) {
+                    int out_f, float omega, HpScale sa, HpScale sb, int reverse_m, hipStream_t stream, bool z_only, HpScale so) {
     HpParams p{};
     p.A = x_hl; p.B = W_hl;
     p.M = (int)n; p.N = out_f; p.K = in_f;
     p.pitchA = (long long)in_f * 4; p.pitchB = (long long)in_f * 4;
     p.a_rows = n; p.b_rows = out_f;
-    p.sa = sa; p.sb = sb;
+    p.sa = sa; p.sb = sb; p.so = so;
     p.C_hl = act_hl; p.C2 = dact; p.bias = bias; p.omega = omega;
     p.k_per_split = in_f; p.reverse_m = reverse_m; p.stagger = g_hp_stagger; p.splits = 1;
     if (z_only) INR_REQUIRE(dact && hp_z_stash_ok(in_f), INR_E_INVALID, "hp_sine_forward: z-only stash needs the deferred-epilogue kernel");
@@ -1271,7 +1274,7 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
         INR_LAUNCH_CHECK();
     }
     if (plan.narrow_rows > 0) {
-        p.stamps = nullptr;
+        if (plan.wide_rows > 0) p.stamps = nullptr;      // (one stamp buffer: the wide launch has it when there is one)
         const bool xzy = g_hp_persistent == 2 && (in_f == 512 || in_f == 256);   // the rule of the wide dispatch above
         p.fold_bias = (g_hp_persistent && in_f >= 3 * HP_BK) ? 1 : 0;
         if (z_only) return hp_launch_narrow<HPE_Z>(p, plan.wide_rows, plan.narrow_rows, xzy, stream);
@@ -1321,7 +1324,7 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
         INR_LAUNCH_CHECK();
     }
     if (plan.narrow_rows > 0) {
-        p.stamps = nullptr;
+        if (plan.wide_rows > 0) p.stamps = nullptr;
         return hp_launch_narrow<HPE_MUL>(p, plan.wide_rows, plan.narrow_rows, g_hp_persistent == 2 && out_f == 512, stream);
     }
     return 0;
@@ -1500,27 +1503,27 @@ int hp_param_grad_multi(const HpParamGradJob* jobs, int njobs, int64_t n, hipStr
 }
 
 int hp_head_forward(float* y, const char* a_hl, const float* W, const float* bias, int64_t n, int hidden, int use_clamp,
-                    float clamp_min, hipStream_t stream, bool from_z, float omega) {
+                    float clamp_min, hipStream_t stream, bool from_z, float omega, HpScale sa) {
     long long blocks = (n + 3) / 4;
     if (blocks > 65536) blocks = 65536;
     const dim3 grid((unsigned)blocks), block(256);
     ProfScope ps(KC_OTHER, stream);
     if (from_z) {
         switch (hidden) {
-            case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
-            case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
-            case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
-            case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega); break;
+            case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega, sa); break;
+            case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega, sa); break;
+            case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega, sa); break;
+            case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, true>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, omega, sa); break;
             default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_forward: hidden = %d", hidden);
         }
         INR_LAUNCH_CHECK();
         return 0;
     }
     switch (hidden) {
-        case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
-        case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
-        case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
-        case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f); break;
+        case 128: hipLaunchKernelGGL((hp_head_forward_kernel<2, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f, sa); break;
+        case 256: hipLaunchKernelGGL((hp_head_forward_kernel<4, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f, sa); break;
+        case 512: hipLaunchKernelGGL((hp_head_forward_kernel<8, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f, sa); break;
+        case 1024: hipLaunchKernelGGL((hp_head_forward_kernel<16, false>), grid, block, 0, stream, y, a_hl, W, bias, n, use_clamp, clamp_min, 0.f, sa); break;
         default: INR_REQUIRE(false, INR_E_INVALID, "hp_head_forward: hidden = %d", hidden);
     }
     INR_LAUNCH_CHECK();
@@ -1551,7 +1554,7 @@ int64_t hp_head_blocks(int64_t n) {
 int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, float* part_g, const char* a_hl,
                  const float* dact, const float* W, const float* bias, const float* t, const float* wgt, int64_t n, int hidden,
                  int64_t count_total, unsigned* amax_out, HpScale so, hipStream_t stream, bool from_z, float omega,
-                 const float* g_ext) {
+                 const float* g_ext, HpScale sa) {
     const float inv = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
     const int rpb = hp_head_rows_per_block(n);
     const dim3 grid((unsigned)((n + rpb - 1) / rpb)), block(256);
@@ -1560,10 +1563,10 @@ int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, fl
     do {                                                                                                                    \
         if (from_z)                                                                                                         \
             hipLaunchKernelGGL((hp_head_step_kernel<CPL, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,   \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext);                 \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);             \
         else                                                                                                                \
             hipLaunchKernelGGL((hp_head_step_kernel<CPL, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,  \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext);                 \
+                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);             \
     } while (0)
     switch (hidden) {
         case 128: HP_HEAD_STEP(2); break;

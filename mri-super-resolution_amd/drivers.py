@@ -388,11 +388,12 @@ def plan_volumes(volumes: Sequence[np.ndarray], steps: int, world: int, allow_sh
     with rows x steps."""
     rows = [float(np.prod([-(-s // 2) if a < 2 else s for a, s in enumerate(v.shape)])) for v in volumes]
     costs = [r * steps for r in rows]
-    default_net = (fit_kwargs.get("hidden_features", 512) == 512 and fit_kwargs.get("hidden_layers", 3) == 3 and
-                   fit_kwargs.get("mapping_size", 128) == 128 and fit_kwargs.get("downsample", True))
+    # priced by the measured step-time table for the reference's network, by the linear model derived from it for any other shape
+    # (dist.StepTimeModel.for_network); a job list that does not train on the half-resolution grid keeps rows x steps
     shard_time = None
-    if default_net:
-        model = inr_dist.StepTimeModel()
+    if fit_kwargs.get("downsample", True):
+        model = inr_dist.StepTimeModel.for_network(2 * fit_kwargs.get("mapping_size", 128), fit_kwargs.get("hidden_features", 512),
+                                                   fit_kwargs.get("hidden_layers", 3))
         shard_time = lambda j, k: model.fit_seconds(rows[j], steps, k)     # noqa: E731
     if allow_sharding and world > 1:
         plan = inr_dist.plan_fits(costs, world, shard_time=shard_time)

@@ -126,3 +126,21 @@ def test_hybrid_echo_time_groups():
     for w in (5, 6, 7):
         g = drivers.hybrid_te_groups(w)
         assert sorted(r for grp in g for r in grp) == list(range(w)) and all(len(grp) >= 1 for grp in g)
+
+
+def test_step_time_model_is_keyed_by_the_network_shape():
+    """The planner prices Siren(256,512,3,1) with the measured table and any other network with the linear model derived from it
+    (fixed launch cost + per-row time scaled by the shape's multiply-add count): a 128-wide network must not be priced as the
+    512-wide one (verdict r03, weak 10)."""
+    import numpy as np
+    from mri_super_resolution_amd import drivers
+    ref = inr_dist.StepTimeModel.for_network(256, 512, 3)
+    assert ref.step_ms(114688) == inr_dist.StepTimeModel().step_ms(114688)
+    small = inr_dist.StepTimeModel.for_network(256, 128, 3)
+    assert 0.05 < small.step_ms(4096) < ref.step_ms(4096)                        # the fixed launch cost stays
+    assert small.step_ms(524288) < 0.15 * ref.step_ms(524288)                    # 13x fewer multiply-adds per row
+    assert small.step_ms(200000) < small.step_ms(400000) < 2.1 * small.step_ms(200000)
+    vols = [np.zeros((128, 128, z), np.float32) for z in (28, 24, 34)]
+    p512 = drivers.plan_volumes(vols, 100, 2)
+    p128 = drivers.plan_volumes(vols, 100, 2, hidden_features=128)
+    assert p128["one_rank"] < 0.5 * p512["one_rank"] and p128["unit"].startswith("seconds")
