@@ -98,6 +98,7 @@ int hp_fused_forward(float* y, const char* x_hl, const unsigned* x_amax, int64_t
                      float hidden_omega, const float* head_W, const float* head_b, int use_clamp, float clamp_min,
                      hipStream_t stream);
 extern tune_int g_hp_zhead;
+extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
                   float* colsum_slab, int* colsum_rows, unsigned* amax_out, HpScale sa, HpScale sb, HpScale so,
@@ -943,6 +944,7 @@ static int fit_forward_backward(const inr_siren_desc_t* d, const Layout& L, cons
 // / 0.181, 8,192: 0.325 / 0.277, 16,384: 0.454 / 0.381, 32,768: 0.674 / 0.630, 69,632: 1.318 / 1.279, 139,264: 2.431 / 2.408,
 // 262,144: 4.42 / 4.42.  (The last bits of the gradients differ between the two forms: other row ranges per partial sum.)
 tune_int g_hp_side_stream{1};   // (the name of the first form; key 20) identical bits either way
+tune_int g_hp_merge_blocks{256};  // key 22: block count the merged parameter-gradient launch aims at (row splits = this / tiles)
 
 // the same step on the pre-split path (gemm_hp.inc): act[l] (l >= 1) and dz are HL32, act[0] = the HL32 image of x,
 // dact fp32 until the backward pass overwrites it with dz (HL32, scaled from an a-priori bound).  Gradients are NOT reduced
@@ -1026,7 +1028,8 @@ static int hp_backward_pass(const inr_siren_desc_t* d, const Layout& L, const fl
     if (merge) {
         long long tiles_all = 0;
         for (int l = 0; l < L.n_sine; ++l) tiles_all += (long long)((L.fan_out[l] + 127) / 128) * ((L.fan_in[l] + 255) / 256);
-        merged_splits = (int)(256 / tiles_all > 1 ? 256 / tiles_all : 1);
+        const int target = g_hp_merge_blocks;
+        merged_splits = (int)(target / tiles_all > 1 ? target / tiles_all : 1);
         const int min_by_len = (int)((n + 16383) / 16384);      // (hp_param_grad_splits: no register accumulation over > 16 k rows)
         if (merged_splits < min_by_len) merged_splits = min_by_len;
     }
@@ -1709,7 +1712,8 @@ const DebugKey* debug_table(int* count) {
         {10, &g_hp_persistent, 2, 0, 2},  {11, &g_hp_stagger, 0, 0, 1 << 20}, {12, &g_small_multi, 1, 0, 1},
         {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 42, 4, 42},
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
-        {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},
+        {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},  {21, &g_hp_head_min_rows, 16, 4, 256},
+        {22, &g_hp_merge_blocks, 256, 28, 1024},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -1540,10 +1540,12 @@ int hp_head_bound_ext(float* head_bound, const unsigned* gmax, const float* head
 
 // rows per block of the head step: at most 256 (what the large fits ran with), fewer when that would leave CUs idle
 // (round 2: 16 blocks at 4,096 rows, 49 us for 8 MB)
+tune_int g_hp_head_min_rows{16};   // inr_debug_set(21, .): fewest rows a block of the head step takes (a multiple of 4)
 int hp_head_rows_per_block(int64_t n) {
     long long r = (n + 1023) / 1024;
     r = (r + 3) / 4 * 4;
-    return (int)(r < 16 ? 16 : (r > 256 ? 256 : r));
+    const int lo = g_hp_head_min_rows;
+    return (int)(r < lo ? lo : (r > 256 ? 256 : r));
 }
 int64_t hp_head_blocks(int64_t n) {
     const int rpb = hp_head_rows_per_block(n);
@@ -1561,12 +1563,18 @@ int hp_head_step(char* dz_hl, float* slab_b, float* slab_w, float* part_loss, fl
     ProfScope ps(KC_OTHER, stream);
 #define HP_HEAD_STEP(CPL)                                                                                                   \
     do {                                                                                                                    \
-        if (from_z)                                                                                                         \
-            hipLaunchKernelGGL((hp_head_step_kernel<CPL, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,   \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);             \
+        if (from_z && g_ext)                                                                                                \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, true, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w,        \
+                               part_loss, part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);  \
+        else if (from_z)                                                                                                    \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, true, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w,       \
+                               part_loss, part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);  \
+        else if (g_ext)                                                                                                     \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, false, true>), grid, block, 0, stream, dz_hl, slab_b, slab_w,       \
+                               part_loss, part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);  \
         else                                                                                                                \
-            hipLaunchKernelGGL((hp_head_step_kernel<CPL, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w, part_loss,  \
-                               part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);             \
+            hipLaunchKernelGGL((hp_head_step_kernel<CPL, false, false>), grid, block, 0, stream, dz_hl, slab_b, slab_w,      \
+                               part_loss, part_g, a_hl, dact, W, bias, t, wgt, n, inv, amax_out, so, rpb, omega, g_ext, sa);  \
     } while (0)
     switch (hidden) {
         case 128: HP_HEAD_STEP(2); break;

@@ -150,6 +150,79 @@ def predict_case(model: RAMS, stack, sample_size=25, rng=None):
     return sr.double().mean(dim=0), subsets
 
 
+# ---- RAMS+ (utils/prediction.py:10-74, 86-97): test-time ensembling.  Tensor plumbing around the forward pass -----------------------
+def _as_dev(x):
+    dev = ops.require_gpu()
+    return torch.as_tensor(np.asarray(x, np.float32) if not torch.is_tensor(x) else x).to(dev, torch.float32)
+
+
+def flip(X, rn=None, rng=None):
+    """prediction.py:54-58: ``rn <= 0.5`` keeps X, otherwise ``tf.image.flip_left_right`` (the W axis: -2); returns
+    (tensor, rint(rn)).  ``rn=None`` draws U[0, 1) from ``rng`` (a ``numpy.random.Generator``; the reference asks TensorFlow's)."""
+    if rn is None:
+        rn = float((rng or np.random.default_rng()).random())
+    X = _as_dev(X)
+    return (X if rn <= 0.5 else torch.flip(X, dims=(-2,))), float(np.rint(rn))
+
+
+def rotate(X, rn=None, rng=None):
+    """prediction.py:61-65: ``tf.image.rot90(X, rn)`` -- counter-clockwise quarter turns of the (H, W) = (-3, -2) axes."""
+    if rn is None:
+        rn = int((rng or np.random.default_rng()).integers(0, 4))
+    X = _as_dev(X)
+    return torch.rot90(X, int(rn) % 4, dims=(-3, -2)), rn
+
+
+def shuffle_last_axis(X, rng=None):
+    """prediction.py:68-73: transpose, shuffle the first axis, transpose back = a random permutation of the LAST axis (the
+    acquisitions).  The permutation comes from ``rng`` (numpy) -- the reference's comes from TensorFlow's global generator."""
+    X = _as_dev(X)
+    perm = (rng or np.random.default_rng()).permutation(X.shape[-1])
+    return X[..., torch.as_tensor(perm, device=X.device)]
+
+
+def geometric_ensemble(X, shuffle=False, rng=None):
+    """prediction.py:32-42: the eight flip x rotation images of one stack [H, W, T] -> ([8, ...], r [8, 2] = (flip, quarter turns))."""
+    r = np.array(np.meshgrid([0, 1], [0, 1, 2, 3])).T.reshape(-1, 2)
+    out = []
+    for i in range(8):
+        a = rotate(flip(X, r[i, 0])[0], r[i, 1])[0]
+        out.append(shuffle_last_axis(a, rng) if shuffle else a)
+    return torch.stack(out), r
+
+
+def random_ensemble(X, n=10, shuffle=True, rng=None):
+    """prediction.py:18-29: n random (flip, rotation) images."""
+    rng = rng or np.random.default_rng()
+    r = np.zeros((n, 2))
+    out = []
+    for i in range(n):
+        a, r[i, 0] = flip(X, rng=rng)
+        a, r[i, 1] = rotate(a, rng=rng)
+        out.append(shuffle_last_axis(a, rng) if shuffle else a)
+    return torch.stack(out), r
+
+
+def ensemble(X, geometric=True, shuffle=False, n=10, rng=None):
+    """prediction.py:10-15 (whose random branch forgets its ``return``: here it returns)."""
+    return geometric_ensemble(X, shuffle, rng) if geometric else random_ensemble(X, n, shuffle, rng)
+
+
+def unensemble(X, r):
+    """prediction.py:45-51: undo rotation (k2 = 4 - k1) and flip of every member, mean over the members (kept as axis 0)."""
+    X = _as_dev(X)
+    members = [flip(rotate(X[i], 4 - int(r[i, 1]))[0], r[i, 0])[0] for i in range(len(X))]
+    return torch.stack(members).double().mean(dim=0, keepdim=True)
+
+
+def predict_tensor_permute(model: RAMS, x, n_ens=10, rng=None):
+    """prediction.py:86-97: ``n_ens`` forward passes of ONE stack [H, W, T] with its acquisitions permuted, clipped and rounded,
+    averaged -> [1, sH, sW, 1].  The permuted stacks run as one batch."""
+    rng = rng or np.random.default_rng()
+    batch = torch.stack([shuffle_last_axis(x, rng) for _ in range(n_ens)])
+    return predict_tensor(model, batch).double().mean(dim=0, keepdim=True)
+
+
 def _shift_loss(y_true, y_pred, y_mask, size, mode):
     dev = ops.require_gpu()
 
@@ -352,3 +425,84 @@ class RamsTrainer:
         self.model.params = self._unflatten(self.flat.cpu().numpy())
         self.model.invalidate()
         return self.model
+
+    # ---- the outer loop (utils/training.py:108-191, 211-220) ---------------------------------------------------------------------
+    def test_step(self, lr_batch, hr, mask):
+        """training.py:211-220: forward (no update), per-image cL1 and the batch's cPSNR."""
+        size = int(np.asarray(hr).shape[1]) if not torch.is_tensor(hr) else int(hr.shape[1])
+        sr = self.sync_model().forward(lr_batch)
+        return l1_loss(hr, sr, mask, HR_SIZE=size), psnr(hr, sr, mask, size_image=size)
+
+    def save_checkpoint(self, directory, psnr_value, max_to_keep=3):
+        """``tf.train.CheckpointManager(max_to_keep=3).save()`` (training.py:88-91, 187): step, best PSNR, variables, Adam state."""
+        import glob
+        import os
+        os.makedirs(directory, exist_ok=True)
+        path = os.path.join(directory, f"ckpt-{self.step_count:08d}.npz")
+        np.savez(path, step=self.step_count, psnr=float(psnr_value), flat=self.flat.cpu().numpy(), m=self.m.cpu().numpy(),
+                 v=self.v.cpu().numpy())
+        for old in sorted(glob.glob(os.path.join(directory, "ckpt-*.npz")))[:-max_to_keep]:
+            os.remove(old)
+        return path
+
+    def restore(self, directory):
+        """training.py:93-97: continue from the latest checkpoint of `directory` if there is one; returns its best PSNR or None."""
+        import glob
+        import os
+        found = sorted(glob.glob(os.path.join(directory, "ckpt-*.npz")))
+        if not found:
+            return None
+        z = np.load(found[-1])
+        dev = self.flat.device
+        self.flat.copy_(torch.from_numpy(z["flat"]).to(dev))
+        self.m.copy_(torch.from_numpy(z["m"]).to(dev))
+        self.v.copy_(torch.from_numpy(z["v"]).to(dev))
+        self.step_count = int(z["step"])
+        self.model.invalidate()
+        return float(z["psnr"])
+
+    def fit(self, x, y, batch_size, epochs=100, evaluate_every=100, val_steps=100, validation_data=None, shuffle=True,
+            initial_epoch=0, save_best_only=True, checkpoint_dir=None, seed=0, log=None):
+        """``Trainer.fit`` (training.py:108-191): ``x`` [n, h, w, T] low-resolution stacks, ``y = (hr, mask)``; per epoch the data in
+        a fresh random order (the reference: ``tf.data`` shuffle with a 512-element buffer, reshuffled each iteration -- a uniform
+        permutation here, seeded), batches of ``batch_size`` (the last one may be short), one ``train_step`` each; every
+        ``evaluate_every`` steps ``test_step`` over at most ``val_steps`` validation batches, and a checkpoint when the mean
+        validation cPSNR improved (or always with ``save_best_only=False``).  Construction-time restore as the reference:
+        ``checkpoint_dir`` holding checkpoints continues from the latest.  Returns the history (one record per evaluation).
+        TensorBoard writers and the progress bar of the reference are replaced by ``log(record)``."""
+        hr, mask = y
+        n = len(x)
+        rng = np.random.default_rng(seed)
+        best = 1.0                                            # training.py:86: psnr = tf.Variable(1.0)
+        if checkpoint_dir:
+            got = self.restore(checkpoint_dir)
+            best = best if got is None else got
+        history, train_losses = [], []
+        for epoch in range(epochs - initial_epoch):
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            for b0 in range(0, n, batch_size):
+                idx = order[b0:b0 + batch_size]
+                train_losses.append(self.train_step(x[idx], hr[idx], mask[idx]).mean())
+                if self.step_count % evaluate_every:
+                    continue
+                rec = {"epoch": epoch + 1 + initial_epoch, "step": self.step_count,
+                       "loss": float(torch.stack(train_losses).mean())}
+                train_losses = []
+                if validation_data is not None:
+                    vx, (vhr, vmask) = validation_data
+                    vorder = rng.permutation(len(vx))
+                    vl, vp = [], []
+                    for k in range(0, min(len(vx), val_steps * batch_size), batch_size):
+                        vi = vorder[k:k + batch_size]
+                        l, p = self.test_step(vx[vi], vhr[vi], vmask[vi])
+                        vl.append(l.mean())
+                        vp.append(p)
+                    rec["val_loss"], rec["val_psnr"] = float(torch.stack(vl).mean()), float(torch.stack(vp).mean())
+                    improved = rec["val_psnr"] > best
+                    if checkpoint_dir and (improved or not save_best_only):
+                        best = rec["val_psnr"]                # (training.py:186: assigned whenever a checkpoint is written)
+                        rec["checkpoint"] = self.save_checkpoint(checkpoint_dir, best)
+                history.append(rec)
+                if log:
+                    log(rec)
+        return history

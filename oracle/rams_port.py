@@ -227,3 +227,25 @@ def keras_adam_step(params, grads, m, v, t, lr=5e-4, b1=0.9, b2=0.999, eps=1e-7)
         m[k] = b1 * m[k] + (1 - b1) * grads[k]
         v[k] = b2 * v[k] + (1 - b2) * grads[k] ** 2
         params[k] = params[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)
+
+
+# ---- RAMS+ ensembling (utils/prediction.py:10-74) restated on numpy: TEST INFRASTRUCTURE like the rest of this file -------------
+def np_flip(X, rn):
+    """prediction.py:54-58 (tf.image.flip_left_right = the W axis, -2)."""
+    return (X if rn <= 0.5 else np.flip(X, axis=-2)), np.rint(rn)
+
+
+def np_rotate(X, k):
+    """prediction.py:61-65 (tf.image.rot90: counter-clockwise quarter turns of (H, W) = axes (-3, -2))."""
+    return np.rot90(X, int(k) % 4, axes=(-3, -2)), k
+
+
+def np_geometric_ensemble(X):
+    """prediction.py:32-42 without the shuffle."""
+    r = np.array(np.meshgrid([0, 1], [0, 1, 2, 3])).T.reshape(-1, 2)
+    return np.stack([np_rotate(np_flip(X, r[i, 0])[0], r[i, 1])[0] for i in range(8)]), r
+
+
+def np_unensemble(X, r):
+    """prediction.py:45-51."""
+    return np.mean([np_flip(np_rotate(X[i], 4 - r[i, 1])[0], r[i, 0])[0] for i in range(len(X))], axis=0, keepdims=True)

