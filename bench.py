@@ -202,7 +202,7 @@ def cfg4_leg(steps=2500):
             "modelled_8_gpu_plan": {"gangs": [[j, r] for j, r in plan8["gangs"]], "whole": plan8["whole"],
                                     "makespan_s": plan8["makespan"], "per_rank_s": plan8["loads"], "one_rank_s_model": plan8["one_rank"]},
             "modelled_note": "makespan from dist.StepTimeModel: per-fit and per-shard step times MEASURED on one GPU "
-                             "(profiles/r03_step_time_table.json), the per-step all-reduce of a row-sharded fit MODELLED (RCCL has "
+                             "(profiles/r04_step_time_table.json), the per-step all-reduce of a row-sharded fit MODELLED (RCCL has "
                              "not run: no multi-GPU node); divided into THIS run's measured one-GPU seconds"}
 
 
@@ -514,7 +514,7 @@ def main():
     # WRITE_SIZE, separate --pmc passes, written by tools/save_profiles.py together with the hash of the kernel sources it
     # was measured on).  A summary taken from other sources is stale: traffic is then null.
     traffic, traffic_by_class, traffic_src, src_hash = None, None, None, source_hash()
-    pmc_path = os.path.join(ROOT, "profiles", "r03_fp32mfma_pmc_hbm.json" if args.fp32_mfma else "r03_pmc_hbm.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_fp32mfma_pmc_hbm.json" if args.fp32_mfma else "r04_pmc_hbm.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as fh:
             pm = json.load(fh)
@@ -575,8 +575,9 @@ def main():
                     "all_gemm_launches": {"achieved_gbps": gbps, "frac_hbm": gbps / PEAK_HBM_GBPS, **common,
                                           "tflops_fp32_equivalent": achieved, "frac_of_fp16_peak_over_3": achieved / mfma_peak},
                     "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "power_note": "peaks are the nominal 2.4 GHz figures; during these steps the package sits at its 1,400 W cap "
-                                  "and the shader clock at ~1.76 GHz (rocm-smi, profiles/r02_power.txt, tools/clock_watch.sh)"}
+                    "power_note": "peaks are the nominal 2.4 GHz figures; during these steps the package sits at its 1,400 W cap and "
+                                  "the shader clock at 1.63 GHz (84 rocm-smi samples over 36 s: profiles/r04_ablate_power.txt; the "
+                                  "K-loop alone holds 2.35 GHz at 1,171 W, the epilogue alone 2.30 GHz at 1,270 W)"}
     ops.prof_reset()
 
     out = {"metric": "voxels/sec per INR fit (128^3, x4 upscale): train coordinate-steps/s",

@@ -4,7 +4,7 @@ nn_mri.py:49-56) and write (``sio.savemat``, automate_INR.py:111).
 Reader: numeric arrays (any numeric class, real), cell arrays (``hybrid_raw`` is a 4 x 4 cell of volumes) and
 compressed elements (``miCOMPRESSED``, zlib).  Writer: numeric N-D arrays and (nested) lists / object arrays as cells,
 uncompressed, little-endian, column-major as MATLAB stores them.  Level-7.3 (HDF5) files -- the reference falls back to
-``mat73`` for those (superresDWI.py:42-43) -- are not MAT-5 and are rejected with a clear error.
+``mat73`` for those (superresDWI.py:42-43) -- are handed to ``mat73io.loadmat73`` (the HDF5 subset MATLAB writes, read without h5py).
 Pure host-side I/O; nothing here touches the device.
 """
 from __future__ import annotations
@@ -80,7 +80,8 @@ def loadmat(path: str) -> Dict[str, np.ndarray]:
     with open(path, "rb") as fh:
         buf = fh.read()
     if buf[:8] == b"\x89HDF\r\n\x1a\n" or buf[:10] == b"MATLAB 7.3":
-        raise MatFormatError(f"{path}: MATLAB 7.3 (HDF5) file, not MAT-5 -- re-save with '-v7' (the reference uses mat73 here)")
+        from .mat73io import loadmat73            # the reference's fallback: `except NotImplementedError: mat73.loadmat(...)`
+        return loadmat73(path)
     if len(buf) < 128 or buf[126:128] != b"IM":
         raise MatFormatError(f"{path}: not a little-endian MAT-5 file")
     out, pos = {}, 128
