@@ -144,10 +144,22 @@ def cfg1_quality(inr, steps=2500, max_seeds=60):
         finals.append(float(res["final_loss"]))
     ours = np.asarray(psnrs, np.float64)
     se = float(np.sqrt(ours.var(ddof=1) / len(ours) + ref_db.var(ddof=1) / len(ref_db)))
+    # spike-robust forms: full-batch Adam at a ~5e-7 loss level spikes, and a fit that ends ON a spike is several dB down for ~50
+    # steps -- the reference's own seed 14 ends at 30.98 dB.  5 %-trimmed means (what tests/test_gpu_cfg4.py holds to 0.05 dB +
+    # 2 se) and medians are what a single such seed does not move.
+    k = max(1, len(ours) // 20)
+    trim = lambda a: np.sort(a)[k:len(a) - k]                                                          # noqa: E731
+    to, tr = trim(ours), trim(ref_db)
+    se_trim = float(np.sqrt(to.var(ddof=1) / len(to) + tr.var(ddof=1) / len(tr)))
+    low = lambda a: [int(i) for i in np.nonzero(a < np.median(a) - 1.0)[0]]                             # noqa: E731
     return {"config": f"pat07 slice 11, 64x64 LR -> 128x128, {steps} steps, {len(seeds)} seeds (those of the reference runs)",
             "psnr_db_mean": float(ours.mean()), "psnr_db_sigma": float(ours.std(ddof=1)),
             "reference_cpu_psnr_db_mean": float(ref_db.mean()), "reference_cpu_psnr_db_sigma": float(ref_db.std(ddof=1)),
             "delta_db": float(ours.mean() - ref_db.mean()), "se_db": se, "n_seeds": len(seeds),
+            "delta_db_trimmed": float(to.mean() - tr.mean()), "se_db_trimmed": se_trim,
+            "delta_db_median": float(np.median(ours) - np.median(ref_db)),
+            "seeds_ending_on_a_spike": {"ours": low(ours), "reference": low(ref_db),
+                                        "rule": "PSNR more than 1 dB under the median of its own series"},
             "psnr_db_trimmed_mean": float(np.sort(ours)[1:-1].mean()),
             "reference_cpu_psnr_db_trimmed_mean": float(np.sort(ref_db)[1:-1].mean()),
             "psnr_db_per_seed": [round(v, 3) for v in psnrs], "reference_cpu_psnr_db_per_seed": [round(float(v), 3) for v in ref_db],

@@ -54,16 +54,16 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
     return groups
 
 
-# Fit-step time of Siren(256,512,3,1) on one MI355X, milliseconds per step by row count: MEASURED in round 3
-# (tools/step_time_table.py -> profiles/r03_step_time_table.json).  `fused` = inr_siren_fit (a whole volume on one rank),
+# Fit-step time of Siren(256,512,3,1) on one MI355X, milliseconds per step by row count: MEASURED (round 4:
+# tools/step_time_table.py -> profiles/r04_step_time_table.json; tests/test_dist_cpu.py holds this table to that file).  `fused` = inr_siren_fit (a whole volume on one rank),
 # `sharded` = inr_siren_loss_grad + inr_adam_step per step (what a gang member runs between two all-reduces).  A step is not
 # linear in the rows: ~0.15 ms of it is fixed (kernel ramp-up / drain of ~16 launches), which is what makes row-sharding cost
 # GPU time -- three 46,421-row shards take 3 x 0.91 = 2.7 ms where the whole 139,264-row volume takes 2.40.
 STEP_TIME_TABLE_MS = (
     # rows, fused, sharded
-    (4096, 0.1806, 0.1842), (16384, 0.3865, 0.3888), (32768, 0.6372, 0.6395), (46421, 0.8670, 0.8707), (65536, 1.1639, 1.1645),
-    (69632, 1.2887, 1.2928), (98304, 1.7301, 1.7287), (114688, 1.9918, 1.9910), (139264, 2.4264, 2.4274),
-    (262144, 4.4722, 4.4645), (524288, 8.8419, 8.8449),
+    (4096, 0.1812, 0.1855), (16384, 0.3857, 0.3899), (32768, 0.6371, 0.6422), (46421, 0.8431, 0.8494),
+    (65536, 1.1551, 1.1578), (69632, 1.2794, 1.2817), (98304, 1.7208, 1.7205), (114688, 1.9843, 1.9871),
+    (139264, 2.4353, 2.4390), (262144, 4.4573, 4.4698), (524288, 8.7863, 8.7951),
 )
 GRADIENT_BYTES = 3_682_320          # flat fp32 gradient of Siren(256,512,3,1) + the loss slot: one all-reduce per step
 
