@@ -32,7 +32,11 @@ from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
-from .matio import MatFormatError
+try:
+    from .matio import MatFormatError
+except ImportError:                               # loaded by path next to a matio.py that was loaded by path (see matio._mat73_module)
+    class MatFormatError(ValueError):
+        pass
 
 _SIG = b"\x89HDF\r\n\x1a\n"
 _UNDEF = 0xFFFFFFFFFFFFFFFF

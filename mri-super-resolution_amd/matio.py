@@ -75,13 +75,35 @@ def _read_matrix(buf, pos, end):
     return name, np.array(arr.reshape(dims, order="F"))
 
 
+def _mat73_module():
+    try:
+        from . import mat73io
+        return mat73io
+    except ImportError:                           # matio.py imported by path (tests do): load the sibling the same way
+        import importlib.util
+        import os
+        import sys
+        name = "_inr_mat73io"
+        if name not in sys.modules:
+            spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(os.path.abspath(__file__)), "mat73io.py"))
+            mod = importlib.util.module_from_spec(spec)
+            sys.modules[name] = mod
+            spec.loader.exec_module(mod)
+        return sys.modules[name]
+
+
 def loadmat(path: str) -> Dict[str, np.ndarray]:
     """``{name: ndarray}`` of a MAT-5 file (numeric arrays, cells as object arrays, strings)."""
     with open(path, "rb") as fh:
         buf = fh.read()
     if buf[:8] == b"\x89HDF\r\n\x1a\n" or buf[:10] == b"MATLAB 7.3":
-        from .mat73io import loadmat73            # the reference's fallback: `except NotImplementedError: mat73.loadmat(...)`
-        return loadmat73(path)
+        mod = _mat73_module()                     # the reference's fallback: `except NotImplementedError: mat73.loadmat(...)`
+        try:
+            return mod.loadmat73(path)
+        except mod.MatFormatError as e:           # (this file loaded on its own, outside the package: another class object)
+            if isinstance(e, MatFormatError):
+                raise
+            raise MatFormatError(str(e)) from None
     if len(buf) < 128 or buf[126:128] != b"IM":
         raise MatFormatError(f"{path}: not a little-endian MAT-5 file")
     out, pos = {}, 128
