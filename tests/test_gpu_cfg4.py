@@ -121,3 +121,39 @@ def test_full_length_fit_quality_t4(golden):
     assert abs(delta) < 0.05 + 2.0 * se, (delta, se)
     assert se < 0.04
     assert sum(v < ref_db.mean() - 0.6 for v in vals) <= 3 and all(v < ref_db.mean() + 0.6 for v in vals), vals
+
+
+def _requeue_worker(rank, world, steps):
+    from tests.conftest import GOLDEN
+    import os
+    from mri_super_resolution_amd import drivers as drv
+    rest = np.load(os.path.join(GOLDEN, "patients_mean_b0.npz"))
+    vols = [rest["pat41"][:, :, :4], rest["pat45"][:, :, :6], rest["pat47"][:, :, :5], rest["pat76"][:, :, :3]]
+    calls = []
+
+    def fit(volume, steps, return_recon=False, **kw):
+        calls.append(int(volume.shape[2]))
+        if rank == 1:
+            raise RuntimeError("injected: this rank's device is gone")
+        fault = (lambda attempt: "nan" if attempt == 0 else None) if volume.shape[2] == 5 else None
+        return drv.fit_volume(volume, steps=steps, return_recon=return_recon, _fault=fault, **kw)
+
+    stats = {}
+    recs = drv.run_volumes(vols, steps=steps, allow_sharding=False, stats=stats, fit_fn=fit, seed=0, chunk_steps=steps)
+    return recs, calls, stats["plan"]["whole"], stats.get("requeued")
+
+
+def test_a_raising_rank_and_a_nan_fit_on_two_ranks(golden):
+    """SURVEY section 5 on real fits, 2 ranks (gloo, both on the test GPU): rank 1 raises on everything it is given -- its
+    volumes are re-run on rank 0 and come back `requeued` -- and one volume's first attempt is poisoned with NaN: re-seeded."""
+    (recs0, calls0, plan0, rq0), (recs1, calls1, plan1, rq1) = run_ranks(_requeue_worker, 2, (12,), timeout=600)
+    assert plan0 == plan1 and rq0 == rq1 == sorted(plan0[1]) and len(plan0[1]) >= 1
+    by = {int(r["job"]): r for r in recs0}
+    assert sorted(by) == [0, 1, 2, 3]
+    for j in range(4):
+        assert by[j]["rank"] == 0.0 and np.isfinite(by[j]["final_loss"]) and np.isfinite(by[j]["psnr_db"])
+        assert by[j]["requeued"] == (1.0 if j in plan0[1] else 0.0)
+    assert by[2]["status"] == drivers.FIT_RESEEDED and by[2]["reseeds"] == 1.0          # the 5-slice volume
+    assert all(by[j]["status"] == drivers.FIT_OK for j in (0, 1, 3))
+    for a, b in zip(recs0, recs1):
+        assert all((a[k] == b[k]) or (a[k] != a[k] and b[k] != b[k]) for k in a)
