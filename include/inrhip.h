@@ -248,7 +248,8 @@ int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, fl
  *                            / d params from the stash of the LAST inr_siren_forward_train on this workspace (INR_E_INVALID when
  *                            there is none, or n differs); gy = dL/dy [n] as autograd hands it over.  `params` must still hold
  *                            the values the forward ran on.  One backward per forward.
- * Workspace: inr_siren_fit_workspace_bytes(desc, n).  Both only enqueue. */
+ * Workspace: inr_siren_fit_workspace_bytes(desc, n).  Both only enqueue.  (What a workspace holds -- a pending forward, an operand
+ * image for the INR_REUSE_* flags -- is remembered on the host for the 64 most recently used workspaces of the process: the least recently used entry makes room.) */
 int inr_siren_hp_eligible(const inr_siren_desc_t* desc);
 int inr_siren_forward_train(const inr_siren_desc_t* desc, const float* params, const float* x, float* y, int64_t n,
                             void* workspace, size_t workspace_bytes, int flags, void* stream);

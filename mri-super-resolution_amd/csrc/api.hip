@@ -1109,18 +1109,25 @@ struct ReuseStamp {
     const void *x = nullptr, *target = nullptr, *weight = nullptr;
     bool image = false, stats = false;
     bool fwd_train = false;      // an inr_siren_forward_train stash is pending (inr_siren_backward_train consumes it)
+    unsigned long long used = 0; // last use (least recently used entry is replaced)
 };
 std::mutex g_reuse_mu;
 ReuseStamp g_reuse[64];
-unsigned g_reuse_next = 0;
+unsigned long long g_reuse_next = 0;
 ReuseStamp* reuse_find(const void* ws, bool create) {      // (caller holds g_reuse_mu)
     for (auto& s : g_reuse)
-        if (s.ws == ws) return &s;
+        if (s.ws == ws) {
+            s.used = ++g_reuse_next;
+            return &s;
+        }
     if (!create) return nullptr;
-    ReuseStamp* s = &g_reuse[g_reuse_next++ % 64];
-    *s = ReuseStamp{};
-    s->ws = ws;
-    return s;
+    ReuseStamp* lru = &g_reuse[0];                          // the least recently used entry makes room
+    for (auto& s : g_reuse)
+        if (s.used < lru->used) lru = &s;
+    *lru = ReuseStamp{};
+    lru->ws = ws;
+    lru->used = ++g_reuse_next;
+    return lru;
 }
 }   // namespace
 

@@ -62,7 +62,7 @@ def fit_health(last_loss: float, recon: Optional[torch.Tensor] = None) -> str:
     return "ok"
 
 
-def fit_volume(volume: np.ndarray, steps: int = 2500, *args, seed: Optional[int] = 0, max_reseeds: int = 1, group=None,
+def fit_volume(volume: np.ndarray, steps: int = 2500, *, seed: Optional[int] = 0, max_reseeds: int = 1, group=None,
                _fault=None, **kwargs) -> Dict[str, object]:
     """``_fit_volume_once`` (the fit itself: arguments there) under the reference's failure rule (``fit_health``): a fit whose
     loss went non-finite or whose reconstruction collapsed to zero is run again from another seed (``seed + 7919 * attempt``: new
@@ -74,8 +74,7 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, *args, seed: Optional[int]
     attempt = 0
     while True:
         s = None if seed is None else seed + 7919 * attempt
-        res = _fit_volume_once(volume, steps, *args, seed=s, group=group,
-                               _poison=bool(_fault and _fault(attempt) == "nan"), **kwargs)
+        res = _fit_volume_once(volume, steps, seed=s, group=group, _poison=bool(_fault and _fault(attempt) == "nan"), **kwargs)
         shared = group is not None and torch.distributed.get_world_size(group) > 1
         health = fit_health(res.get("final_loss"), None if shared else res.get("_recon_probe"))
         res.pop("_recon_probe", None)
@@ -473,7 +472,7 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
             mine = []
             for r in failed:                               # longest first, each to the survivor that is free first
                 k = min(survivors, key=lambda q: (busy[q], q))
-                busy[k] += r["n_coords"] * steps * 1e-9
+                busy[k] += r["n_coords"] * steps / 5.5e7      # (seconds at the fused step's ~55 M coordinate-steps/s)
                 if k == rank:
                     mine.append(int(r["job"]))
             local.clear()

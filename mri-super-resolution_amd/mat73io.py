@@ -215,7 +215,7 @@ class _File:
         btree, = struct.unpack_from("<Q", self.buf, p + 3)
         chunk = struct.unpack_from(f"<{ndim}I", self.buf, p + 11)[:-1]
         pipeline = next((self.filters(b) for t, b, s in msgs if t == 0x000B), [])
-        out = np.zeros(dims, dtype=f"V{itemsize}") if False else bytearray(total)
+        out = bytearray(total)
         view = np.frombuffer(out, dtype=np.uint8).reshape(tuple(dims) + (itemsize,))
         if btree == _UNDEF:
             return bytes(out)
