@@ -334,6 +334,14 @@ def loadmat73(path: str) -> Dict[str, object]:
     as object arrays (``value[b][te]`` works as there) instead of nested lists."""
     with open(path, "rb") as fh:
         buf = fh.read()
+    try:
+        return _load(buf, path)
+    except (struct.error, IndexError, KeyError, zlib.error, UnicodeDecodeError, OverflowError) as e:
+        # a truncated or damaged file walks off a structure: say what it is instead of leaking the parser's exception
+        raise MatFormatError(f"{path}: damaged or truncated MATLAB 7.3 file ({type(e).__name__}: {e})") from None
+
+
+def _load(buf: bytes, path: str) -> Dict[str, object]:
     f = _File(buf, path)
     if f.root.get("cache") == 1:
         members = f.group_members(f.root["btree"], f.root["heap"])

@@ -72,6 +72,10 @@ def test_load_mat_volume_reads_a_v73_file_and_rejections(tmp_path):
     bad.write_bytes(b"MATLAB 7.3 MAT-file".ljust(512) + b"not an hdf5 file at all".ljust(256))
     with pytest.raises(matio.MatFormatError, match="superblock"):
         matio.loadmat(str(bad))
+    cut = open(path, "rb").read()[:900]                        # truncated behind the superblock: a format error, not an IndexError
+    (tmp_path / "cut.mat").write_bytes(cut)
+    with pytest.raises(matio.MatFormatError, match="damaged or truncated|superblock|signature"):
+        matio.loadmat(str(tmp_path / "cut.mat"))
     # a version-2 object header (newer libver, not MATLAB): named, not mis-read
     good = bytearray(open(path, "rb").read())
     from mri_super_resolution_amd.mat73io import _File
