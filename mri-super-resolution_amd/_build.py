@@ -19,6 +19,12 @@ LIB_PATH = os.path.join(PKG_DIR, "libinrhip.so")
 SOURCES = ("api.hip", "gemm_f32.hip", "kernels.hip", "metrics.hip", "rams.hip", "siren_small.hip",
            "hybrid_fit.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+# Per-source code-generation flags.  The GEMM translation unit is compiled WITHOUT packed fp32 VALU instructions (v_pk_mul_f32 /
+# v_pk_fma_f32): beside MFMAs they cost the deferred-epilogue GEMM 3 % (profiles/r04_nt_ab.txt); its VALU-bound kernels switch them
+# back on one by one (INR_PACKED_F32 in csrc/gemm_hp.inc -- a kernel with the feature can inline helpers compiled without it, not
+# the other way round, which is why the default is set here and not by an attribute on the GEMM kernels).
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+SOURCE_FLAGS = {"gemm_f32.hip": NO_PACKED_F32}
 
 
 def _headers():
@@ -34,25 +40,40 @@ def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     built = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in _sources()] + _headers()
+    deps = [os.path.join(CSRC, f) for f in _sources()] + _headers() + [os.path.abspath(__file__)]   # the flags live in this file
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build_diagnostic(defines=("-DINR_STAMPS",), out=None, verbose=False) -> str:
+def build_diagnostic(defines=("-DINR_STAMPS",), out=None, verbose=False, source_flags=True) -> str:
     """A diagnostic build (time stamps, ablations) into its OWN file -- never over the product library.  Select it with
-    ``INR_LIB=<path>``; ``inr_build_flags()`` of such a library is non-zero and the binding refuses it otherwise."""
+    ``INR_LIB=<path>``; ``inr_build_flags()`` of such a library is non-zero and the binding refuses it otherwise.
+    ``source_flags=False`` drops SOURCE_FLAGS (the A/B partner of the product's code-generation choices)."""
+    import tempfile
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = out or os.path.join(PKG_DIR, "libinrhip_diag.so")
     tmp = f"{out}.tmp.{os.getpid()}"
-    cmd = [hipcc] + FLAGS + list(defines) + ["-shared", "-I", INCLUDE, "-I", CSRC, "-o", tmp] + \
-        [os.path.join(CSRC, s) for s in _sources()]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    with tempfile.TemporaryDirectory(dir=PKG_DIR, prefix="_diag_obj_") as objdir:
+        jobs, objs = [], []
+        for src in _sources():
+            obj = os.path.join(objdir, src.replace(".hip", ".o"))
+            extra = SOURCE_FLAGS.get(src, []) if source_flags else []
+            jobs.append([hipcc] + FLAGS + extra + list(defines) + ["-I", INCLUDE, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj])
+            objs.append(obj)
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd))
+            return subprocess.run(cmd, capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as pool:
+            for res in pool.map(run, jobs):
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+        res = run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        if res.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("link failed:\n" + res.stdout + res.stderr)
     os.replace(tmp, out)          # readers only ever see a complete file
     return out
 
@@ -79,13 +100,13 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 
 def _build_locked(hipcc: str, force: bool, verbose: bool) -> str:
-    newest_header = max(os.path.getmtime(h) for h in _headers())
+    newest_header = max(os.path.getmtime(h) for h in _headers() + [os.path.abspath(__file__)])
     jobs = []
     for src in _sources():
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(path), newest_header):
-            jobs.append([hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC, "-c", path, "-o", obj])
+            jobs.append([hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + ["-I", INCLUDE, "-I", CSRC, "-c", path, "-o", obj])
 
     def run(cmd):
         if verbose:

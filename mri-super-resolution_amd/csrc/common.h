@@ -47,6 +47,10 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 static inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- per-kernel-class event profiler (bench.py roofline) ---------------------------------------
+// gemm_f32.hip is compiled without packed fp32 VALU instructions (_build.py: SOURCE_FLAGS -- they slow the MFMA kernels' epilogues);
+// kernels with no MFMA beside their VALU work switch them back on.  A no-op in translation units built with the default feature set.
+#define INR_PACKED_F32 __attribute__((target("packed-fp32-ops")))
+
 // inputs of the split-fp16 GEMM path (gemm_h3.inc); a null pointer / default-constructed value selects the fp32 MFMA
 struct H3Args {
     const unsigned* a_amax = nullptr;   // float bits of max|A| (dz operands); null: A unscaled (activations, |A| <= 1)

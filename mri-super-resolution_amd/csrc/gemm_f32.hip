@@ -237,7 +237,7 @@ __device__ __forceinline__ void load_tile(f32x4 (&reg)[4], const float* __restri
 }
 
 template <bool A_KC, bool B_KC, int EPI, bool VEC>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(NTHREADS, 2) INR_PACKED_F32 gemm_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (TileSize<A_KC>::floats + TileSize<B_KC>::floats)];
     constexpr int STAGE = TileSize<A_KC>::floats + TileSize<B_KC>::floats;
     constexpr int BOFF = TileSize<A_KC>::floats;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, float* __rest
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(NTHREADS, 2) INR_PACKED_F32 gemm_f32_pipe_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * (TileSize<A_KC>::floats + TileSize<B_KC>::floats)];
     constexpr int STAGE = TileSize<A_KC>::floats + TileSize<B_KC>::floats;
     constexpr int BOFF = TileSize<A_KC>::floats;
@@ -703,7 +703,7 @@ constexpr int SUB16 = 68;                       // epilogue stage row stride (fl
 constexpr int STAGE16_FLOATS = 4 * 64 * SUB16;  // four waves x 64 rows
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ void __launch_bounds__(NTHREADS, 2) gemm_f32_pipe16_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(NTHREADS, 2) INR_PACKED_F32 gemm_f32_pipe16_kernel(const GemmParams p) {
     constexpr int STAGE = TileSize16<A_KC>::floats + TileSize16<B_KC>::floats;
     constexpr int BOFF = TileSize16<A_KC>::floats;
     constexpr int SMEM = (2 * STAGE > STAGE16_FLOATS) ? 2 * STAGE : STAGE16_FLOATS;
@@ -1341,7 +1341,7 @@ struct HlGrid {
     int dim;
     long long n[8];
 };
-__global__ void __launch_bounds__(256) grid_fourier_hl_kernel(char* __restrict__ out, HlGrid g, long long row_begin, long long n_rows,
+__global__ void __launch_bounds__(256) INR_PACKED_F32 grid_fourier_hl_kernel(char* __restrict__ out, HlGrid g, long long row_begin, long long n_rows,
                                                               const float* __restrict__ B, int m, unsigned* __restrict__ x_amax) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t == 0) *x_amax = 0x3f800000u;                       // max(1, max|x|) = 1: what tensor_amax would have found

@@ -32,6 +32,8 @@ def source_hash():
         if f.endswith((".hip", ".inc", ".h")):
             with open(os.path.join(d, f), "rb") as fh:
                 h.update(f.encode() + b"\0" + fh.read())
+    with open(os.path.join(root, "mri-super-resolution_amd", "_build.py"), "rb") as fh:      # the compiler flags are part of the code
+        h.update(b"_build.py\0" + fh.read())
     return h.hexdigest()[:16]
 
 
