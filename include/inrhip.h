@@ -410,7 +410,8 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * it pays; 0 = one launch per layer, in line; the gradients' last bits differ between the two: other row ranges per partial sum;
  * inr_launch_count counts every GEMM of the merged launch); key 21 = fewest rows a block of the fused head step takes (16 default;
  * 4 .. 256, multiples of 4: more, smaller blocks at small row counts); key 22 = block count the merged parameter-gradient launch
- * aims at (256 default = one round over the chip; its row splits are this over the layers' tile count);
+ * aims at (256 default = one round over the chip; its row splits are this over the layers' tile count); key 23 = rows per block of
+ * the fused head step (0 default = the library's rule, at most 128; set it before the workspace of a fit is sized);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

@@ -98,6 +98,7 @@ int hp_fused_forward(float* y, const char* x_hl, const unsigned* x_amax, int64_t
                      float hidden_omega, const float* head_W, const float* head_b, int use_clamp, float clamp_min,
                      hipStream_t stream);
 extern tune_int g_hp_zhead;
+extern tune_int g_hp_head_rows;
 extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
@@ -1720,7 +1721,7 @@ const DebugKey* debug_table(int* count) {
         {13, &g_small_rows, 0, 0, 64},    {14, &g_rams_mode, 2, 0, 7},      {15, &g_rams_lds_waves, 42, 4, 42},
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
         {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},  {21, &g_hp_head_min_rows, 16, 4, 256},
-        {22, &g_hp_merge_blocks, 256, 28, 1024},
+        {22, &g_hp_merge_blocks, 256, 28, 1024}, {23, &g_hp_head_rows, 0, 0, 4096},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -824,7 +824,7 @@ int gemm_build_flags() {
 #endif
     if (H3_ABLATE != 0 || HP_ABLATE != 0) f |= 2;
     if (H3_EXTRA_LDS != 0) f |= 4;
-    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1) f |= 8;     // cache-policy experiments (gemm_hp.inc)
+    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1 || HP_HEAD_PREFETCH != 1) f |= 8;     // cache-policy experiments (gemm_hp.inc)
     return f;
 }
 static unsigned long long* hp_stamp_target(int kernel_class) {
@@ -1539,14 +1539,18 @@ int hp_head_bound_ext(float* head_bound, const unsigned* gmax, const float* head
     return 0;
 }
 
-// rows per block of the head step: at most 256 (what the large fits ran with), fewer when that would leave CUs idle
-// (round 2: 16 blocks at 4,096 rows, 49 us for 8 MB)
+// rows per block of the head step: at most 128, fewer when that would leave CUs idle (round 2: 16 blocks at 4,096 rows, 49 us for
+// 8 MB).  128, not the 256 of rounds 1-3: at 78 VGPRs six blocks share a CU, and 2,048 blocks on 1,536 slots are 1.33 rounds --
+// 4,096 blocks leave a shorter tail (profiles/r04_nt_ab.txt, box 8: 0.542 ms per step outside the GEMMs against 0.551; 64 rows
+// 0.546, 344 rows = one block per slot 0.576)
 tune_int g_hp_head_min_rows{16};   // inr_debug_set(21, .): fewest rows a block of the head step takes (a multiple of 4)
+tune_int g_hp_head_rows{0};        // inr_debug_set(23, .): rows per block of the head step, 0 = the rule below
 int hp_head_rows_per_block(int64_t n) {
+    if (g_hp_head_rows > 0) return (g_hp_head_rows + 3) / 4 * 4;
     long long r = (n + 1023) / 1024;
     r = (r + 3) / 4 * 4;
     const int lo = g_hp_head_min_rows;
-    return (int)(r < lo ? lo : (r > 256 ? 256 : r));
+    return (int)(r < lo ? lo : (r > 128 ? 128 : r));
 }
 int64_t hp_head_blocks(int64_t n) {
     const int rpb = hp_head_rows_per_block(n);
