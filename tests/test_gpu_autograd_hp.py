@@ -144,6 +144,21 @@ def test_accumulation_pending_forwards_and_inplace_inputs(golden):
     assert O.rel_l2(host(b), host(want)) < 1e-6 and O.rel_l2(host(a), host(b)) > 1e-2
     (b.sum()).backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    # a NEW batch tensor at the address (and version counter) of the one the previous step freed -- what a mini-batch loop does --
+    # is not the tensor whose operand image the workspace holds
+    net.zero_grad()
+    outs, ptrs = [], []
+    for k in range(3):
+        xb = x * (1.0 - 0.25 * k)                                              # fresh tensor each step, freed after its backward
+        ptrs.append(xb.data_ptr())
+        yb = net(xb)
+        outs.append(yb.detach().clone())
+        yb.sum().backward()
+        del xb, yb
+    with torch.no_grad():
+        for k in range(3):
+            assert O.rel_l2(host(outs[k]), host(net(x * (1.0 - 0.25 * k)))) < 1e-6, (k, ptrs)
+    assert O.rel_l2(host(outs[0]), host(outs[1])) > 1e-2
 
 
 def test_reference_loop_verbatim_ten_steps(golden):
