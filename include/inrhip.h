@@ -411,7 +411,9 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * inr_launch_count counts every GEMM of the merged launch); key 21 = fewest rows a block of the fused head step takes (16 default;
  * 4 .. 256, multiples of 4: more, smaller blocks at small row counts); key 22 = block count the merged parameter-gradient launch
  * aims at (256 default = one round over the chip; its row splits are this over the layers' tile count); key 23 = rows per block of
- * the fused head step (0 default = the library's rule, at most 128; set it before the workspace of a fit is sized);
+ * the fused head step (0 default = the library's rule, at most 128; set it before the workspace of a fit is sized); key 24 = RAMS
+ * training step: 1 (default) the data-gradient convolutions apply the ReLU mask / add the residual gradient in their epilogue,
+ * 0 = separate element-wise passes (bit-identical);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

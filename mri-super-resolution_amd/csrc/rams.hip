@@ -639,11 +639,17 @@ static int rams_lds_blocks_per_b(int B, int npatch) {
                 "RAMS convolution: %d channel-sum slabs per batch element x %d do not fit the %lld floats planned for them",    \
                 (int)(rows_per_b), B, slab_cap)
 
+// the epilogue-operand forms (AUX) exist for the default kernel only; tune key 24 = 0 keeps the training step on the separate passes
+tune_int g_rams_epi_fuse{1};
+static inline bool rams_lds_aux_ok() { return g_rams_lds_waves == 42 && g_rams_epi_fuse != 0; }
 extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_debug_set_ptr(0, device buffer of 16 x u64)
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
                          const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
-                         int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st, long long slab_cap = -1) {
+                         int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st, long long slab_cap = -1,
+                         const float* aux = nullptr, int aux_mode = 0) {
+    INR_REQUIRE(aux_mode == 0 || (aux && rams_lds_aux_ok()), INR_E_INVALID, "RAMS convolution: epilogue operand without the default kernel");
     Conv3dLdsParams p{};
+    p.aux = aux;
     p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
@@ -666,7 +672,9 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
         if (blocks > p.np1 * p.np2) blocks = p.np1 * p.np2;
         if (nslab) *nslab = blocks * 4;
         R3L_SLAB_GUARD(blocks * 4);
-        hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true>), dim3(blocks, B), dim3(256), 0, st, p);
+        if (aux_mode == 1) hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true, 1>), dim3(blocks, B), dim3(256), 0, st, p);
+        else if (aux_mode == 2) hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true, 2>), dim3(blocks, B), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true>), dim3(blocks, B), dim3(256), 0, st, p);
     } else if (two_pass) {
         if (nslab) *nslab = blocks * 8;
         R3L_SLAB_GUARD(blocks * 8);

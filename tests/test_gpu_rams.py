@@ -265,6 +265,28 @@ def test_train_gradients_match_autograd(conv_mode):
     assert total < 1e-5, total
 
 
+def test_epilogue_fused_backward_is_bit_identical():
+    """Training step: the data-gradient convolutions apply the ReLU mask (with the masked gradient's maximum) and add the residual
+    path's gradient in their epilogue (debug key 24 = 1, default) -- the same bits as the separate element-wise passes (key 24 = 0),
+    at a batch whose images take border AND interior patches."""
+    from mri_super_resolution_amd._lib import lib
+    params = R.init_rams_params(seed=5, perturb_g=True)
+    x, hr, mask = _train_case(B=3, side=24, seed=11)
+    got = {}
+    try:
+        for key in (1, 0):
+            lib().inr_debug_set(24, key)
+            trainer = rams.RamsTrainer(rams.RAMS(3, 32, 3, 9, 8, 12, params=params))
+            loss, _ = trainer.loss_and_grads(x, hr, mask, want_prediction=True)
+            got[key] = (loss.cpu().numpy().copy(), {k: np.array(v, copy=True) for k, v in trainer.named_gradients().items()})
+    finally:
+        lib().inr_debug_set(24, 1)
+    assert np.array_equal(got[0][0], got[1][0])
+    for k in got[0][1]:
+        assert np.array_equal(got[0][1][k], got[1][1][k]), k
+    assert any(np.abs(v).max() > 0 for v in got[1][1].values())
+
+
 @pytest.mark.parametrize("conv_mode", [2, 0], indirect=True)
 def test_train_steps_follow_keras_adam(conv_mode):
     """Ten train_steps on a small RAMS (N = 2): the loss trajectory against the float64 restatement + Keras-form Adam, on both
