@@ -413,7 +413,8 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * aims at (256 default = one round over the chip; its row splits are this over the layers' tile count); key 23 = rows per block of
  * the fused head step (0 default = the library's rule, at most 128; set it before the workspace of a fit is sized); key 24 = RAMS
  * training step: 1 (default) the data-gradient convolutions apply the ReLU mask / add the residual gradient in their epilogue,
- * 0 = separate element-wise passes (bit-identical);
+ * 0 = separate element-wise passes (bit-identical); key 25 = tall slab reductions (more than 128 partial sums per output) in one
+ * launch (1, default) or two (0; the same additions in the same order);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

@@ -335,6 +335,21 @@ __global__ void __launch_bounds__(256) colsum_kernel(float* __restrict__ slab, c
     }
 }
 
+// sum of x[s * pitch], s in [s0, s1): four running sums over s mod 4 (the remainder into the first), then (a0 + a1) + (a2 + a3) --
+// THE order of every slab reduction here
+__device__ __forceinline__ float slab_run_sum(const float* x, int s0, int s1, int64_t pitch) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 3 < s1; s += 4) {
+        a0 += x[(int64_t)s * pitch];
+        a1 += x[(int64_t)(s + 1) * pitch];
+        a2 += x[(int64_t)(s + 2) * pitch];
+        a3 += x[(int64_t)(s + 3) * pitch];
+    }
+    for (; s < s1; ++s) a0 += x[(int64_t)s * pitch];
+    return (a0 + a1) + (a2 + a3);
+}
+
 // out[g][i] = sum_{s in group g} slab[s][i]  (fixed order; group g = slabs [g*per_group, (g+1)*per_group))
 // grid = (ceil(len/256), groups).  With groups == 1 this is the plain slab reduction.
 // (slab s starts at slab + s * pitch: pitch == len for a dense stack, larger for partials interleaved with other fields)
@@ -344,16 +359,22 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(float* __restrict__ o
     if (i >= len) return;
     const int s0 = blockIdx.y * per_group;
     const int s1 = min(nslabs, s0 + per_group);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = s0;
-    for (; s + 3 < s1; s += 4) {
-        a0 += slab[(int64_t)s * pitch + i];
-        a1 += slab[(int64_t)(s + 1) * pitch + i];
-        a2 += slab[(int64_t)(s + 2) * pitch + i];
-        a3 += slab[(int64_t)(s + 3) * pitch + i];
-    }
-    for (; s < s1; ++s) a0 += slab[(int64_t)s * pitch + i];
-    out[(int64_t)blockIdx.y * len + i] = (a0 + a1) + (a2 + a3);
+    out[(int64_t)blockIdx.y * len + i] = slab_run_sum(slab + i, s0, s1, pitch);
+}
+
+// Both stages of a tall reduction in ONE launch: 64 outputs per block, four threads per output take the groups of
+// REDUCE_GROUP slabs in turn (group sums through LDS), one of them adds the group sums -- the additions of the two-launch
+// form in its order (slab_run_sum over a group's slabs, then over the group sums), so the same bits.  groups <= 32.
+__global__ void __launch_bounds__(256) reduce_slabs_onepass_kernel(float* __restrict__ out, const float* __restrict__ slab,
+                                                                   int nslabs, int64_t len, int per_group, int64_t pitch) {
+    __shared__ float part[32][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + o;
+    const int groups = (nslabs + per_group - 1) / per_group;
+    if (i < len)
+        for (int g = q; g < groups; g += 4) part[g][o] = slab_run_sum(slab + i, g * per_group, min(nslabs, (g + 1) * per_group), pitch);
+    __syncthreads();
+    if (q == 0 && i < len) out[i] = slab_run_sum(&part[0][o], 0, groups, 64);
 }
 
 // ---- deferred reduction + loss + Adam of a fused step (common.h: FinalizeJob) ---------------------------------------------
@@ -678,6 +699,7 @@ int launch_colsum(float* out, const float* X, const float* g, int64_t n, int C, 
 // tall-and-narrow slab stacks (thousands of slabs of a few hundred floats) are reduced in two stages so the
 // sum is spread over many blocks; `tmp` must hold reduce_tmp_floats(nslabs, len) floats and not overlap `slab`.
 constexpr int REDUCE_GROUP = 32;
+tune_int g_reduce_onepass{1};      // inr_debug_set(25, 0): tall reductions in two launches (the form of rounds 1-3; same bits)
 int64_t reduce_tmp_floats(int64_t nslabs, int64_t len) {
     return nslabs > 4 * REDUCE_GROUP ? (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP * len : 0;
 }
@@ -690,6 +712,12 @@ int launch_reduce_slabs_pitched(float* out, const float* slab, int nslabs, int64
         return 0;
     }
     const int groups = (nslabs + REDUCE_GROUP - 1) / REDUCE_GROUP;
+    if (groups <= 32 && g_reduce_onepass) {      // (tmp stays unused)
+        hipLaunchKernelGGL(reduce_slabs_onepass_kernel, dim3(blocks_for(len, 64, 1 << 30), 1), dim3(256), 0, st, out, slab, nslabs, len,
+                           REDUCE_GROUP, pitch);
+        INR_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, groups), dim3(256), 0, st, tmp, slab, nslabs, len, REDUCE_GROUP, pitch);
     INR_LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, 1), dim3(256), 0, st, out, tmp, groups, len, groups, len);
