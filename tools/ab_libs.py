@@ -23,6 +23,15 @@ def step_ms(n, k, fp32=False):
     cls = [ops.prof_read(c) for c in range(4)]
     lib().inr_debug_set(3, 1)
     return dt, [round(ms / max(nl, 1), 4) for nl, ms in cls[:3]] + [round(cls[3][1] / k, 4)]
+def signature(n):      # a short deterministic fit: the bits two builds must share when a change claims "the same bits"
+    import hashlib
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = (torch.rand(n, 256, device="cuda", generator=g) * 2 - 1).contiguous(); t = torch.rand(n, device="cuda", generator=g)
+    torch.manual_seed(0)
+    f = inr.SirenFitter(inr.Siren(256, 512, 3, 1).cuda(), lr=1e-4)
+    losses = f.step(x, t, 12); torch.cuda.synchronize()
+    return hashlib.sha256(f.flat.detach().cpu().numpy().tobytes() + losses.detach().cpu().numpy().tobytes()).hexdigest()[:12]
+out["sig"] = [signature(4096), signature(150016)]
 out["step128"], out["classes(fwd,dx,dw,other/step)"] = step_ms(524288, 30)
 out["fp32_128"], _ = step_ms(524288, 8, True)
 out["step4096"], _ = step_ms(4096, 300)
