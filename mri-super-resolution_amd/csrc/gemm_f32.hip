@@ -824,7 +824,7 @@ int gemm_build_flags() {
 #endif
     if (H3_ABLATE != 0 || HP_ABLATE != 0) f |= 2;
     if (H3_EXTRA_LDS != 0) f |= 4;
-    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1 || HP_HEAD_PREFETCH != 1) f |= 8;     // cache-policy experiments (gemm_hp.inc)
+    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1 || HP_HEAD_PREFETCH != 1 || HP_COLSUM_TRANSPOSED != 1) f |= 8;     // cache-policy experiments (gemm_hp.inc)
     return f;
 }
 static unsigned long long* hp_stamp_target(int kernel_class) {
