@@ -21,8 +21,6 @@ from __future__ import annotations
 import itertools
 import math
 
-import weakref
-
 import numpy as np
 import torch
 from torch import nn
@@ -232,7 +230,7 @@ class _TrainState:
         self.flat = None
         self._views = []
         self._free_ws = None          # a workspace no pending forward owns
-        self._last = None             # ((workspace data_ptr, x data_ptr, x._version, n), weakref to x) of the last forward
+        self._last = None             # ((workspace data_ptr, x data_ptr, x._version, n, strides), x) of the last forward: x kept alive
 
     def ensure(self):
         params = self.model.layer_parameters()
@@ -282,13 +280,14 @@ class _SirenHpFn(torch.autograd.Function):
         x = x.contiguous()
         n = x.shape[0]
         ws = state.take_workspace(n, x.device)
-        # The operand image of x is reused only for the SAME tensor object, unmodified: a data pointer alone says nothing -- a batch
-        # tensor freed after one step hands its address (and a version counter of 0) to the next step's batch
-        key = (ws.data_ptr(), x.data_ptr(), x._version, n)
-        last = state._last
-        same = last is not None and last[0] == key and last[1]() is x
+        # The operand image of x is reused when the same memory, unmodified, comes again.  A data pointer and a version counter alone
+        # do not say that -- a batch tensor freed after one step hands its address (and a version counter of 0) to the next step's
+        # batch -- so the state KEEPS the last input alive (one tensor view; `Siren.forward` makes a new view object per call, so the
+        # Python object's identity says nothing either): while it lives, nothing else can own that address.
+        key = (ws.data_ptr(), x.data_ptr(), x._version, n, tuple(x.stride()))
+        same = state._last is not None and state._last[0] == key
         y, ws = ops.siren_forward_train(state.desc, state.flat, x, ws, ops.REUSE_INPUT_IMAGE if same else 0)
-        state._last = (key, weakref.ref(x))
+        state._last = (key, x)
         ctx.state, ctx.ws, ctx.x = state, ws, x          # (x kept alive: the backward's layer-0 GEMM reads its operand image only,
         return y                                         #  but the C side remembers the pointer)
 

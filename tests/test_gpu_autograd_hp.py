@@ -120,14 +120,24 @@ def test_matches_the_layer_by_layer_path_and_the_fused_fit(golden):
         assert O.rel_l2(gw, hp[names[2 * l]]) < 1e-6, names[2 * l]        # same kernels; only dL/dy is formed elsewhere
 
 
-def test_accumulation_pending_forwards_and_inplace_inputs(golden):
+def test_accumulation_pending_forwards_and_inplace_inputs(golden, monkeypatch):
     net, x, d = _net(golden)
     t = dev(d["lr_pixels"][0])
+    flags_seen = []
+    real_forward_train = ops.siren_forward_train
+
+    def spy(desc, flat, xx, ws, flags=0):
+        flags_seen.append(int(flags))
+        return real_forward_train(desc, flat, xx, ws, flags)
+
+    monkeypatch.setattr(ops, "siren_forward_train", spy)
     ((net(x) - t) ** 2).mean().backward()
     once = {n: p.grad.clone() for n, p in net.named_parameters()}
     ((net(x) - t) ** 2).mean().backward()                                      # accumulates into .grad
     for n, p in net.named_parameters():
         assert torch.allclose(p.grad, 2 * once[n], rtol=1e-6, atol=0), n
+    # the loop of the reference hands the SAME input every step (through a fresh .detach() view): its operand image is reused
+    assert flags_seen == [0, ops.REUSE_INPUT_IMAGE], flags_seen
     net.zero_grad()
     x2 = x.flip(0).contiguous()
     y1, y2 = net(x), net(x2)                                                   # two forwards pending, backward through both
@@ -155,6 +165,7 @@ def test_accumulation_pending_forwards_and_inplace_inputs(golden):
         outs.append(yb.detach().clone())
         yb.sum().backward()
         del xb, yb
+    assert flags_seen[-3:] == [0, 0, 0], flags_seen          # (no batch was taken for the previous one)
     with torch.no_grad():
         for k in range(3):
             assert O.rel_l2(host(outs[k]), host(net(x * (1.0 - 0.25 * k)))) < 1e-6, (k, ptrs)
