@@ -148,6 +148,25 @@ def test_compat_modules_import():
     assert nn_mri.Siren(2, 8, 1, 1).return_coords is True
 
 
+def test_per_source_compiler_flags_name_real_sources_and_reach_the_source_hash():
+    """`_build.SOURCE_FLAGS` (the GEMM translation unit is compiled without packed fp32 VALU instructions) must name sources that
+    exist -- a typo would silently build the default feature set -- and the compiler flags are part of what bench.py's kernel-source
+    hash covers (a tracked PMC summary measured with other flags must read as stale)."""
+    import hashlib
+    import bench
+    from mri_super_resolution_amd import _build
+    assert set(_build.SOURCE_FLAGS) <= set(_build.SOURCES) and "gemm_f32.hip" in _build.SOURCE_FLAGS
+    assert "-packed-fp32-ops" in _build.SOURCE_FLAGS["gemm_f32.hip"]
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(_build.__file__), "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".inc", ".h")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    without_flags = h.hexdigest()[:16]
+    assert bench.source_hash() != without_flags and len(bench.source_hash()) == 16
+
+
 def test_debug_switches_are_validated_readable_and_resettable():
     """The diagnostic switches: unknown keys and out-of-range values are refused, a value can be read back, and one call
     restores every default (what tests/conftest.py does after each test)."""
@@ -159,11 +178,12 @@ def test_debug_switches_are_validated_readable_and_resettable():
     assert lib.inr_debug_set(10, 3) == _lib.INR_E_INVALID and b"takes 0 .. 2" in lib.inr_last_error()
     assert lib.inr_debug_set(4, 1) == _lib.INR_E_INVALID and b"unknown key" in lib.inr_last_error()
     assert lib.inr_debug_get(99, ctypes.byref(v)) == _lib.INR_E_INVALID
-    for key, val in ((0, 1), (3, 0), (7, 0), (12, 0), (14, 5), (16, 0), (17, 1), (18, 0)):
+    for key, val in ((0, 1), (3, 0), (7, 0), (12, 0), (14, 5), (16, 0), (17, 1), (18, 0), (21, 8), (22, 128), (23, 64), (24, 0), (25, 0)):
         assert lib.inr_debug_set(key, val) == 0, key
+    assert lib.inr_debug_set(24, 2) == _lib.INR_E_INVALID and lib.inr_debug_set(23, 5000) == _lib.INR_E_INVALID
     assert lib.inr_debug_reset() == 0
     for key, default in ((0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (6, 1), (7, 1), (10, 2), (11, 0), (12, 1), (13, 0), (14, 2),
-                         (15, 42), (16, 1), (17, 0), (18, 1), (19, 0), (20, 1)):
+                         (15, 42), (16, 1), (17, 0), (18, 1), (19, 0), (20, 1), (21, 16), (22, 256), (23, 0), (24, 1), (25, 1)):
         assert lib.inr_debug_get(key, ctypes.byref(v)) == 0 and v.value == default, (key, v.value)
     n = ctypes.c_int64(-1)
     assert lib.inr_launch_counts_reset() == 0
