@@ -1031,13 +1031,19 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     }
     // one 3-D convolution (either arithmetic); xs = slot of max|x|, ys = slot that receives max|y| (nullable)
     int last_nslab = 0;      // channel-sum slabs the last convolution wrote per batch element
+    // add (nullable): the staged kernel adds this tensor to its output in the epilogue (rams_h3.inc, AUX 1); *added says whether it did
     auto conv3d = [&](const float* xin, float* yout, const float* w, const float* bias, float* chan, const unsigned* xs,
-                      unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb) -> int {
+                      unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb,
+                      const float* add = nullptr, bool* added = nullptr) -> int {
         const int k = conv_no++;
         last_nslab = wpb;
-        if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3))
+        if (added) *added = false;
+        if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3)) {
+            const bool with_add = add && added && rams_lds_aux_ok();
+            if (added) *added = with_add;
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
-                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap);
+                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap, with_add ? add : nullptr, with_add ? 1 : 0);
+        }
         if (h3)
             return conv3d_h3(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3, pad,
                              cout, cstride, relu, wpb, st);
@@ -1094,11 +1100,22 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     {   // trunk close + long skip (network.py:127-129)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
         const int wpb = rams_waves_per_b(B, D1 * D2 * D3);
-        if (int rc = conv3d(bufA, bufB, w, b, nullptr, io_slot, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
+        // the long skip rides in the convolution's epilogue (conv + stem output, the operands and order of add_v4_kernel: same bits;
+        // 0.28 ms per 25 stacks); the sum then lives in bufB, so the two buffers change names
+        unsigned* sum_slot = h3 ? new_slot() : nullptr;
+        bool added = false;
+        if (int rc = conv3d(bufA, bufB, w, b, nullptr, io_slot, sum_slot, D1, D2, D3, 1, RC, RC, 0, wpb, bufR, &added)) return rc;
         const long long total = (long long)B * D1 * D2 * D3 * RC;
-        io_slot = h3 ? new_slot() : nullptr;
-        hipLaunchKernelGGL(add_v4_kernel, dim3(2048), dim3(256), 0, st, bufA, bufB, bufR, total / 4, io_slot);
-        INR_LAUNCH_CHECK();
+        if (added) {
+            float* t = bufA;
+            bufA = bufB;
+            bufB = t;
+        } else {
+            if (sum_slot) INR_HIP(hipMemsetAsync(sum_slot, 0, R3_SLOT * sizeof(unsigned), st));   // (it holds max|conv|, not max|sum|)
+            hipLaunchKernelGGL(add_v4_kernel, dim3(2048), dim3(256), 0, st, bufA, bufB, bufR, total / 4, sum_slot);
+            INR_LAUNCH_CHECK();
+        }
+        io_slot = sum_slot;
     }
     for (int i = 0; i < T / 3; ++i) {   // temporal reduction (network.py:132-136)
         hipLaunchKernelGGL(reflect_pad_v4_kernel, dim3((D1 + 2) * (D2 + 2), B), dim3(256), 0, st, bufP, bufA, D1, D2, D3 * RC / 4);

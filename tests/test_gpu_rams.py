@@ -265,6 +265,24 @@ def test_train_gradients_match_autograd(conv_mode):
     assert total < 1e-5, total
 
 
+def test_long_skip_in_the_convolution_epilogue_is_bit_identical():
+    """Inference: the trunk-closing convolution adds the stem output in its epilogue (debug key 24 = 1, default) instead of a separate
+    add pass (key 24 = 0): the same bits, at a batch with border and interior patches and at batch 1."""
+    from mri_super_resolution_amd._lib import lib
+    model = rams.RAMS(3, 32, 3, 9, 8, 12, params=R.init_rams_params(seed=4, perturb_g=True))
+    rng = np.random.default_rng(2)
+    try:
+        for shape in ((3, 40, 36, 9), (1, 64, 64, 9)):
+            x = torch.from_numpy((rng.random(shape) * 30000 + 500).astype(np.float32)).cuda()
+            out = {}
+            for key in (1, 0):
+                lib().inr_debug_set(24, key)
+                out[key] = model(x).clone()
+            assert torch.equal(out[0], out[1]) and float(out[1].abs().max()) > 0
+    finally:
+        lib().inr_debug_set(24, 1)
+
+
 def test_epilogue_fused_backward_is_bit_identical():
     """Training step: the data-gradient convolutions apply the ReLU mask (with the masked gradient's maximum) and add the residual
     path's gradient in their epilogue (debug key 24 = 1, default) -- the same bits as the separate element-wise passes (key 24 = 0),
