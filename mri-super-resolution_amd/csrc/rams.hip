@@ -348,6 +348,28 @@ __global__ void __launch_bounds__(256) reflect_pad_v4_kernel(float* __restrict__
     for (int k = threadIdx.x; k < inner4; k += 256) dst[k] = src[k];
 }
 
+// the frame of a reflect-padded image whose interior is already in place (written there by the convolution, Conv3dLdsParams::y_pad):
+// buf [B][D1 + 2][D2 + 2][inner]; one frame voxel per block column -- top and bottom rows first, then the two side columns
+__global__ void __launch_bounds__(256) reflect_border_v4_kernel(float* __restrict__ buf, int D1, int D2, int inner4) {
+    const int f = blockIdx.x, b = blockIdx.y, W2 = D2 + 2;
+    int o1, o2;
+    if (f < 2 * W2) {
+        o1 = f < W2 ? 0 : D1 + 1;
+        o2 = f < W2 ? f : f - W2;
+    } else {
+        const int gidx = f - 2 * W2;
+        o1 = 1 + gidx % D1;
+        o2 = gidx < D1 ? 0 : D2 + 1;
+    }
+    int i1 = o1 - 1, i2 = o2 - 1;
+    i1 = i1 < 0 ? -i1 : (i1 >= D1 ? 2 * D1 - 2 - i1 : i1);
+    i2 = i2 < 0 ? -i2 : (i2 >= D2 ? 2 * D2 - 2 - i2 : i2);
+    f32x4* img = reinterpret_cast<f32x4*>(buf) + (long long)b * (D1 + 2) * W2 * inner4;
+    const f32x4* src = img + ((long long)(i1 + 1) * W2 + (i2 + 1)) * inner4;
+    f32x4* dst = img + ((long long)o1 * W2 + o2) * inner4;
+    for (int k = threadIdx.x; k < inner4; k += 256) dst[k] = src[k];
+}
+
 __global__ void __launch_bounds__(256) add_v4_kernel(float* __restrict__ out, const float* __restrict__ a,
                                                      const float* __restrict__ b, long long total4, unsigned* amax) {
     float m = 0.f;
@@ -646,10 +668,12 @@ extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_d
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
                          const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
                          int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st, long long slab_cap = -1,
-                         const float* aux = nullptr, int aux_mode = 0) {
+                         const float* aux = nullptr, int aux_mode = 0, int y_pad = 0) {
     INR_REQUIRE(aux_mode == 0 || (aux && rams_lds_aux_ok()), INR_E_INVALID, "RAMS convolution: epilogue operand without the default kernel");
+    INR_REQUIRE(y_pad == 0 || (aux_mode == 0 && g_rams_lds_waves == 42), INR_E_INVALID, "RAMS convolution: padded output without the default kernel");
     Conv3dLdsParams p{};
     p.aux = aux;
+    p.y_pad = y_pad;
     p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
@@ -663,7 +687,8 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
     p.stamps = g_stamps;
     p.mD3 = r3_magic(D3); p.mHP2 = r3_magic(p.PO2 + 2); p.mO3 = r3_magic(p.O3); p.mPO2 = r3_magic(p.PO2);
     p.mNP2 = r3_magic(p.np2);
-    INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 30) && (long long)p.O1 * p.O2 * p.O3 * y_cstride * 4 < (1ll << 30),
+    INR_REQUIRE((long long)D1 * D2 * D3 * RC * 4 < (1ll << 30) &&
+                    (long long)(p.O1 + 2 * y_pad) * (p.O2 + 2 * y_pad) * p.O3 * y_cstride * 4 < (1ll << 30),
                 INR_E_INVALID, "RAMS convolution: an image of %d x %d x %d x 32 floats exceeds the kernel's 1 GiB per image", D1, D2, D3);
     int blocks = rams_lds_blocks_per_b(B, p.np1 * p.np2);
     ProfScope ps(KC_OTHER, st);
@@ -1034,15 +1059,20 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     // add (nullable): the staged kernel adds this tensor to its output in the epilogue (rams_h3.inc, AUX 1); *added says whether it did
     auto conv3d = [&](const float* xin, float* yout, const float* w, const float* bias, float* chan, const unsigned* xs,
                       unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb,
-                      const float* add = nullptr, bool* added = nullptr) -> int {
+                      const float* add = nullptr, bool* added = nullptr, bool* padded = nullptr) -> int {
+        // padded (nullable): the caller would like the output written as the interior of a reflect-padded image (y_pad); *padded: done
         const int k = conv_no++;
         last_nslab = wpb;
         if (added) *added = false;
+        if (padded) *padded = false;
         if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3)) {
             const bool with_add = add && added && rams_lds_aux_ok();
+            const bool with_pad = padded && !with_add && rams_lds_aux_ok();
             if (added) *added = with_add;
+            if (padded) *padded = with_pad;
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
-                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap, with_add ? add : nullptr, with_add ? 1 : 0);
+                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap, with_add ? add : nullptr, with_add ? 1 : 0,
+                                 with_pad ? 1 : 0);
         }
         if (h3)
             return conv3d_h3(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3, pad,
@@ -1117,16 +1147,32 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         }
         io_slot = sum_slot;
     }
+    bool have_padded = false;           // bufP already holds the next stage's padded input (written there by the previous stage)
     for (int i = 0; i < T / 3; ++i) {   // temporal reduction (network.py:132-136)
-        hipLaunchKernelGGL(reflect_pad_v4_kernel, dim3((D1 + 2) * (D2 + 2), B), dim3(256), 0, st, bufP, bufA, D1, D2, D3 * RC / 4);
-        INR_LAUNCH_CHECK();
+        if (!have_padded) {
+            hipLaunchKernelGGL(reflect_pad_v4_kernel, dim3((D1 + 2) * (D2 + 2), B), dim3(256), 0, st, bufP, bufA, D1, D2, D3 * RC / 4);
+            INR_LAUNCH_CHECK();
+        }
         if (int rc = rfab(bufP, D1 + 2, D2 + 2, D3)) return rc;      // (reflect padding copies values: max|.| carries over)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
         const int wpb = rams_waves_per_b(B, D1 * D2 * (D3 - 2));
         unsigned* out_slot = h3 ? new_slot() : nullptr;
-        if (int rc = conv3d(bufP, bufA, w, b, nullptr, io_slot, out_slot, D1 + 2, D2 + 2, D3, 0, RC, RC, 1, wpb)) return rc;
+        // every stage but the last feeds another padded block: its convolution writes the interior of that padded image itself and
+        // a kernel over the frame completes it (the values reflect_pad_v4_kernel would have copied: same bits; 0.2 ms per 25 stacks each)
+        bool padded = false;
+        if (int rc = conv3d(bufP, bufA, w, b, nullptr, io_slot, out_slot, D1 + 2, D2 + 2, D3, 0, RC, RC, 1, wpb, nullptr, nullptr,
+                            i + 1 < T / 3 ? &padded : nullptr))
+            return rc;
         io_slot = out_slot;
         D3 -= 2;
+        have_padded = padded;
+        if (padded) {
+            hipLaunchKernelGGL(reflect_border_v4_kernel, dim3(2 * (D2 + 2) + 2 * D1, B), dim3(256), 0, st, bufA, D1, D2, D3 * RC / 4);
+            INR_LAUNCH_CHECK();
+            float* t = bufA;
+            bufA = bufP;
+            bufP = t;
+        }
     }
     {   // up-scaling head: Conv3D 32 -> scale^2, valid; keep T index 0 (network.py:139-140)
         const float* w = c.take(CONV_W_FLOATS); const float* b = c.take(RC);
