@@ -348,6 +348,61 @@ __global__ void __launch_bounds__(256) reflect_pad_v4_kernel(float* __restrict__
     for (int k = threadIdx.x; k < inner4; k += 256) dst[k] = src[k];
 }
 
+// The stem by rows: one thread = four output channels of ALL D3 voxels of a (b, i1, i2) row.  Per (d1, d2) it loads the D3 + 2
+// values of the neighbouring row once (zeros past the ends) and three weight quads, and every output takes its taps in the order
+// (d1, d2, d3) conv3d_c1_v4_kernel takes them -- the same bits (a tap outside the image adds 0 * w there, nothing here: the same sum)
+// with 14 loads per voxel instead of 54 (the per-voxel kernel was bound by its L1 round trips: 0.62 ms per 25 stacks for 0.9 GB).
+template <int TD>      // D3 (compile time: the window lives in registers)
+__global__ void __launch_bounds__(256) conv3d_c1_rows_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                             const float* __restrict__ w, const float* __restrict__ bias, int B,
+                                                             int D1, int D2, unsigned* amax, float* __restrict__ y2) {
+    const long long rows = (long long)B * D1 * D2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (i < rows * (RC / 4)) {
+        const int c4 = (int)(i % (RC / 4));
+        long long v = i / (RC / 4);
+        const int i2 = (int)(v % D2); v /= D2;
+        const int i1 = (int)(v % D1);
+        const int b = (int)(v / D1);
+        f32x4 acc[TD];
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * c4);
+#pragma unroll
+        for (int t = 0; t < TD; ++t) acc[t] = bv;
+#pragma unroll
+        for (int d1 = 0; d1 < 3; ++d1)
+#pragma unroll
+            for (int d2 = 0; d2 < 3; ++d2) {
+                const int j1 = i1 + d1 - 1, j2 = i2 + d2 - 1;
+                if ((unsigned)j1 >= (unsigned)D1 || (unsigned)j2 >= (unsigned)D2) continue;      // (the per-voxel kernel skips these taps too)
+                const float* xr = x + (((long long)b * D1 + j1) * D2 + j2) * TD;
+                float xv[TD];
+#pragma unroll
+                for (int t = 0; t < TD; ++t) xv[t] = xr[t];
+                f32x4 wv[3];
+#pragma unroll
+                for (int d3 = 0; d3 < 3; ++d3) wv[d3] = *reinterpret_cast<const f32x4*>(w + ((d1 * 3 + d2) * 3 + d3) * RC + 4 * c4);
+#pragma unroll
+                for (int t = 0; t < TD; ++t)
+#pragma unroll
+                    for (int d3 = 0; d3 < 3; ++d3) {
+                        const int j3 = t + d3 - 1;
+                        if (j3 < 0 || j3 >= TD) continue;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][q] = fmaf(xv[j3], wv[d3][q], acc[t][q]);
+                    }
+            }
+        const long long o4 = ((((long long)b * D1 + i1) * D2 + i2) * TD) * (RC / 4) + c4;
+#pragma unroll
+        for (int t = 0; t < TD; ++t) {
+            reinterpret_cast<f32x4*>(y)[o4 + (long long)t * (RC / 4)] = acc[t];
+            if (y2) reinterpret_cast<f32x4*>(y2)[o4 + (long long)t * (RC / 4)] = acc[t];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmaxf(m, fabsf(acc[t][q]));
+        }
+    }
+    if (amax) r3_block_amax(m, amax);
+}
 // the frame of a reflect-padded image whose interior is already in place (written there by the convolution, Conv3dLdsParams::y_pad):
 // buf [B][D1 + 2][D2 + 2][inner]; one frame voxel per block column -- top and bottom rows first, then the two side columns
 __global__ void __launch_bounds__(256) reflect_border_v4_kernel(float* __restrict__ buf, int D1, int D2, int inner4) {
@@ -545,6 +600,26 @@ __global__ void __launch_bounds__(256) shuffle_sum_kernel(float* __restrict__ ou
 // =============================== host orchestration ====================================================
 static inline unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
 static inline unsigned nblk_capped(long long total) { const unsigned b = nblk(total); return b < 2048u ? b : 2048u; }   // grid-stride kernels
+// debug key 24: 1 (default) = the round-4 fusions and kernels -- epilogue operands of the staged convolution (AUX: default kernel
+// only), padded outputs, the stem by rows; 0 = the separate passes / per-voxel stem they replaced (the same bits: the tests compare)
+tune_int g_rams_epi_fuse{1};
+// the stem launch: rows kernel for the depths the network uses, the per-voxel kernel otherwise (a, w, bias 16-byte aligned)
+static void launch_stem(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, unsigned* amax,
+                        float* y2, hipStream_t st) {
+    const long long row_threads = (long long)B * D1 * D2 * (RC / 4);
+    const dim3 rgrid((unsigned)((row_threads + 255) / 256));
+    if (g_rams_epi_fuse == 0) D3 = -D3;      // (no rows kernel for a negative depth)
+    if (D3 == 9) hipLaunchKernelGGL(conv3d_c1_rows_kernel<9>, rgrid, dim3(256), 0, st, y, x, w, bias, B, D1, D2, amax, y2);
+    else if (D3 == 7) hipLaunchKernelGGL(conv3d_c1_rows_kernel<7>, rgrid, dim3(256), 0, st, y, x, w, bias, B, D1, D2, amax, y2);
+    else if (D3 == 5) hipLaunchKernelGGL(conv3d_c1_rows_kernel<5>, rgrid, dim3(256), 0, st, y, x, w, bias, B, D1, D2, amax, y2);
+    else if (D3 == 3) hipLaunchKernelGGL(conv3d_c1_rows_kernel<3>, rgrid, dim3(256), 0, st, y, x, w, bias, B, D1, D2, amax, y2);
+    else {
+        D3 = D3 < 0 ? -D3 : D3;
+        hipLaunchKernelGGL(conv3d_c1_v4_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * (RC / 4))), dim3(256), 0, st, y, x, w, bias, B, D1,
+                           D2, D3, amax, y2);
+    }
+}
+
 
 struct RamsLayout {
     // offsets (floats) into the packed parameter buffer; see inr_rams_param_offsets
@@ -661,8 +736,6 @@ static int rams_lds_blocks_per_b(int B, int npatch) {
                 "RAMS convolution: %d channel-sum slabs per batch element x %d do not fit the %lld floats planned for them",    \
                 (int)(rows_per_b), B, slab_cap)
 
-// the epilogue-operand forms (AUX) exist for the default kernel only; tune key 24 = 0 keeps the training step on the separate passes
-tune_int g_rams_epi_fuse{1};
 static inline bool rams_lds_aux_ok() { return g_rams_lds_waves == 42 && g_rams_epi_fuse != 0; }
 extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_debug_set_ptr(0, device buffer of 16 x u64)
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
@@ -1121,8 +1194,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     {   // stem (network.py:119)
         const float* w = c.take(27 * RC); const float* b = c.take(RC);
         io_slot = h3 ? new_slot() : nullptr;
-        hipLaunchKernelGGL(conv3d_c1_v4_kernel, dim3(nblk((long long)B * D1 * D2 * D3 * (RC / 4))), dim3(256), 0, st, bufA, xpad,
-                           w, b, B, D1, D2, D3, io_slot, bufR);
+        launch_stem(bufA, xpad, w, b, B, D1, D2, D3, io_slot, bufR, st);
         INR_LAUNCH_CHECK();     // (bufR: the stem output kept for the long skip)
     }
     for (int i = 0; i < d->n_rfab; ++i)
