@@ -412,9 +412,12 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * 4 .. 256, multiples of 4: more, smaller blocks at small row counts); key 22 = block count the merged parameter-gradient launch
  * aims at (256 default = one round over the chip; its row splits are this over the layers' tile count); key 23 = rows per block of
  * the fused head step (0 default = the library's rule, at most 128; set it before the workspace of a fit is sized); key 24 = RAMS
- * training step: 1 (default) the data-gradient convolutions apply the ReLU mask / add the residual gradient in their epilogue,
- * 0 = separate element-wise passes (bit-identical); key 25 = tall slab reductions (more than 128 partial sums per output) in one
- * launch (1, default) or two (0; the same additions in the same order);
+ * kernels: 1 = the fusions that keep every bit (training: the data-gradient convolutions apply the ReLU mask / add the residual
+ * gradient in their epilogue; inference: long skip in the trunk-closing convolution's epilogue, padded outputs, the stem by rows),
+ * 0 = the separate passes they replaced, 2 (default) = also the inference gate of an attention block computed from its first
+ * convolution's output so that the second applies it and adds the residual itself (equal up to the rounding of a mean); key 25 = tall slab reductions (more than 128 partial sums per output) in one
+ * launch (1, default) or two (0; the same additions in the same order); key 26 = fewest voxels (batch x image) for which RAMS
+ * inference takes the gate-ahead form of key 24 = 2 (600,000 default: four 128 x 128 x 9 stacks);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

@@ -101,6 +101,7 @@ extern tune_int g_hp_zhead;
 extern tune_int g_hp_head_rows;
 extern tune_int g_rams_epi_fuse;       // key 24 (rams.hip)
 extern tune_int g_reduce_onepass;      // key 25 (kernels.hip)
+extern tune_int g_rams_pregate_min_vox;   // key 26 (rams.hip)
 extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
@@ -1724,7 +1725,8 @@ const DebugKey* debug_table(int* count) {
         {16, &g_hp_zhead, 1, 0, 1},       {17, &g_small_spin_limit, 0, 0, 1 << 30}, {18, &g_hp_narrow, 1, 0, 1},
         {19, &g_hp_fused_fwd, 0, 0, 1},  {20, &g_hp_side_stream, 1, 0, 1},  {21, &g_hp_head_min_rows, 16, 4, 256},
         {22, &g_hp_merge_blocks, 256, 28, 1024}, {23, &g_hp_head_rows, 0, 0, 4096},
-        {24, &g_rams_epi_fuse, 1, 0, 1}, {25, &g_reduce_onepass, 1, 0, 1},
+        {24, &g_rams_epi_fuse, 2, 0, 2}, {25, &g_reduce_onepass, 1, 0, 1},
+        {26, &g_rams_pregate_min_vox, 600000, 0, 1 << 30},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

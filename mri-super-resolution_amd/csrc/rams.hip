@@ -245,6 +245,168 @@ __global__ void __launch_bounds__(1024) gate_kernel(float* __restrict__ gate, co
     }
 }
 
+// ---- the gate of an attention block BEFORE its second convolution runs ------------------------------------------------------
+// gate = f(mean over voxels of c2), c2 = conv2(r1) + b2 ('same', zero padding) -- and that mean is linear in r1:
+//   sum_v c2[v][co] = V b2[co] + sum_tap sum_ci W2[tap][ci][co] S[tap][ci],   S[tap][ci] = sum of r1[.][ci] over the box of voxels
+// tap (d1, d2, d3) reaches from inside the image: all of an axis for d = 1, all but the last index for d = 0, all but the first for
+// d = 2.  The 27 boxes are unions of the 27 classes (first / middle / last index per axis) of a voxel; the class sums of r1 need
+// the whole-tensor sum (the first convolution's epilogue leaves it, as it does for the gate of the other form) and the boundary
+// classes: the two depth faces of every interior row (2 of D3 voxels) and the thin H / W frame.  With the gate known, the second
+// convolution applies it and adds the residual in its epilogue (rams_h3.inc, AUX 4): c2 is never written, the scale_residual pass
+// (three tensor passes at 5.3 TB/s = 16 % of a batch-25 forward) is gone.  Equal to the other form up to the rounding of the mean.
+constexpr int RCLS_NB = 64;      // blocks per batch element of the class-sum kernel
+// part [B][RCLS_NB][27][32] (class = 9 a1 + 3 a2 + a3, a = 0 first / 1 middle / 2 last index; class 13 = all-middle is not formed here)
+__global__ void __launch_bounds__(256) rams_class_sums_kernel(float* __restrict__ part_out, const float* __restrict__ r1, int D1,
+                                                              int D2, int D3) {
+    __shared__ float part[8][17][32];
+    const int b = blockIdx.y, k = blockIdx.x, c = threadIdx.x & 31, ph = threadIdx.x >> 5;
+    const float* img = r1 + (long long)b * D1 * D2 * D3 * RC + c;
+    auto vox = [&](int i1, int i2, int t) { return img[(((long long)i1 * D2 + i2) * D3 + t) * RC]; };
+    const int n1 = D1 - 2, n2 = D2 - 2;
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) acc[i] = 0.f;
+    // interior rows: the two depth faces (32-bit indices: the host checks the image size; four rows' loads in flight, added in order)
+    {
+        const unsigned nrow = (unsigned)n1 * (unsigned)n2, step = RCLS_NB * 8;
+        unsigned r = (unsigned)k * 8 + ph;
+        for (; r + 3 * step < nrow; r += 4 * step) {
+            float a[4], z[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned rr = r + u * step, q1 = rr / (unsigned)n2;
+                a[u] = vox(1 + (int)q1, 1 + (int)(rr - q1 * n2), 0);
+                z[u] = vox(1 + (int)q1, 1 + (int)(rr - q1 * n2), D3 - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0] += a[u];
+                acc[1] += z[u];
+            }
+        }
+        for (; r < nrow; r += step) {
+            const unsigned q1 = r / (unsigned)n2;
+            acc[0] += vox(1 + (int)q1, 1 + (int)(r - q1 * n2), 0);
+            acc[1] += vox(1 + (int)q1, 1 + (int)(r - q1 * n2), D3 - 1);
+        }
+    }
+    // the four edges of the H / W frame (corners apart): whole depth rows, split by depth class
+    auto row3 = [&](int i1, int i2, float& s0, float& s1, float& s2) {
+        s0 += vox(i1, i2, 0);
+        for (int t = 1; t < D3 - 1; ++t) s1 += vox(i1, i2, t);
+        s2 += vox(i1, i2, D3 - 1);
+    };
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int len = e < 2 ? n2 : n1;
+        for (int q = k * 8 + ph; q < len; q += RCLS_NB * 8) {
+            const int i1 = e == 0 ? 0 : e == 1 ? D1 - 1 : 1 + q, i2 = e == 2 ? 0 : e == 3 ? D2 - 1 : 1 + q;
+            row3(i1, i2, acc[2 + 3 * e], acc[3 + 3 * e], acc[4 + 3 * e]);
+        }
+    }
+    if (k == 0 && ph < 4) row3((ph & 2) ? D1 - 1 : 0, (ph & 1) ? D2 - 1 : 0, acc[14], acc[15], acc[16]);
+#pragma unroll
+    for (int i = 0; i < 17; ++i) part[ph][i][c] = acc[i];
+    __syncthreads();
+    float* out = part_out + ((long long)b * RCLS_NB + k) * 27 * RC;
+    for (int i = threadIdx.x; i < 27 * RC; i += 256) {
+        const int cls = i / RC, cc = i % RC, a1 = cls / 9, a2 = (cls / 3) % 3, a3 = cls % 3;
+        float v = 0.f;
+        int slot = -1;        // which of the 14 per-block sums this class is; corners sit with ONE phase group each
+        if (a1 == 1 && a2 == 1) slot = a3 == 0 ? 0 : a3 == 2 ? 1 : -1;
+        else if (a1 == 0 && a2 == 1) slot = 2 + a3;
+        else if (a1 == 2 && a2 == 1) slot = 5 + a3;
+        else if (a1 == 1 && a2 == 0) slot = 8 + a3;
+        else if (a1 == 1 && a2 == 2) slot = 11 + a3;
+        if (slot >= 0) {
+            for (int g = 0; g < 8; ++g) v += part[g][slot][cc];
+        } else if (!(a1 == 1 && a2 == 1)) {
+            v = part[(a1 ? 2 : 0) + (a2 ? 1 : 0)][14 + a3][cc];          // (zeros in every block but the first)
+        }
+        out[i] = v;
+    }
+}
+
+// gate [B][C] from the class sums; one block of 1,024 threads per batch element.  tot_slab [B][nslab][32]: partial whole-tensor sums
+// of r1 (the convolution's channel slabs); w2 [27][32][32], b2 [32]: the SECOND convolution's kernel and bias
+__global__ void __launch_bounds__(1024) gate_pre_kernel(float* __restrict__ gate, const float* __restrict__ tot_slab, int nslab,
+                                                        const float* __restrict__ cls_part, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float inv_count,
+                                                        const float* __restrict__ wsq, const float* __restrict__ bsq,
+                                                        const float* __restrict__ wex, const float* __restrict__ bex, int Cr) {
+    __shared__ float Cs[27][32], Ss[27][32], part[32][32], tot[32], mean[32], sq[8];
+    const int b = blockIdx.x, t = threadIdx.x, c = t % 32, ph = t / 32;
+    {   // whole-tensor sums (gate_kernel's first phase)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float* base = tot_slab + (long long)b * nslab * RC + c;
+        int s = ph;
+        for (; s + 96 < nslab; s += 128) {
+            a0 += base[(long long)s * RC];
+            a1 += base[(long long)(s + 32) * RC];
+            a2 += base[(long long)(s + 64) * RC];
+            a3 += base[(long long)(s + 96) * RC];
+        }
+        for (; s < nslab; s += 32) a0 += base[(long long)s * RC];
+        part[ph][c] = (a0 + a1) + (a2 + a3);
+    }
+    if (t < 27 * RC) {   // boundary class sums over the blocks of the class-sum kernel, eight loads in flight, fixed order
+        const float* src = cls_part + (long long)b * RCLS_NB * 27 * RC + t;
+        float v = 0.f;
+        for (int k = 0; k < RCLS_NB; k += 8) {
+            float u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = src[(long long)(k + q) * 27 * RC];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += u[q];
+        }
+        Cs[t / RC][t % RC] = v;
+    }
+    __syncthreads();
+    if (t < RC) {
+        float m = 0.f;
+        for (int k = 0; k < 32; ++k) m += part[k][t];
+        float others = 0.f;
+        for (int cls = 0; cls < 27; ++cls)
+            if (cls != 13) others += Cs[cls][t];
+        tot[t] = m;
+        Cs[13][t] = m - others;
+    }
+    __syncthreads();
+    if (t < 27 * RC) {   // box sums: axis classes {0, 1} for d = 0, all for d = 1, {1, 2} for d = 2
+        const int tap = t / RC, ci = t % RC, d1 = tap / 9, d2 = (tap / 3) % 3, d3 = tap % 3;
+        float v = 0.f;
+        for (int a1 = (d1 == 2); a1 <= 2 - (d1 == 0); ++a1)
+            for (int a2 = (d2 == 2); a2 <= 2 - (d2 == 0); ++a2)
+                for (int a3 = (d3 == 2); a3 <= 2 - (d3 == 0); ++a3) v += Cs[a1 * 9 + a2 * 3 + a3][ci];
+        Ss[tap][ci] = v;
+    }
+    __syncthreads();
+    {   // sum_tap sum_ci W2[tap][ci][co] S[tap][ci]: 864 terms over 32 phase groups of 27
+        const float* Sf = &Ss[0][0];
+        float v = 0.f;
+        for (int j = 0; j < 27; ++j) v = fmaf(w2[(long long)(ph * 27 + j) * RC + c], Sf[ph * 27 + j], v);
+        part[ph][c] = v;
+    }
+    __syncthreads();
+    if (t < RC) {
+        float m = 0.f;
+        for (int k = 0; k < 32; ++k) m += part[k][t];
+        mean[t] = fmaf(m, inv_count, b2[t]);
+    }
+    __syncthreads();
+    if (t < Cr) {
+        float s = bsq[t];
+        for (int k = 0; k < RC; ++k) s = fmaf(mean[k], wsq[k * Cr + t], s);
+        sq[t] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    if (t < RC) {
+        float e = bex[t];
+        for (int k = 0; k < Cr; ++k) e = fmaf(sq[k], wex[k * RC + t], e);
+        gate[b * RC + t] = 1.0f / (1.0f + expf(-e));
+    }
+}
+
 // out = y * gate[b][c] + res   over [B][per_b voxels][C]
 __global__ void __launch_bounds__(256) scale_residual_kernel(float* __restrict__ out, const float* __restrict__ y,
                                                              const float* __restrict__ gate, const float* __restrict__ res,
@@ -600,9 +762,11 @@ __global__ void __launch_bounds__(256) shuffle_sum_kernel(float* __restrict__ ou
 // =============================== host orchestration ====================================================
 static inline unsigned nblk(long long total) { return (unsigned)((total + 255) / 256); }
 static inline unsigned nblk_capped(long long total) { const unsigned b = nblk(total); return b < 2048u ? b : 2048u; }   // grid-stride kernels
-// debug key 24: 1 (default) = the round-4 fusions and kernels -- epilogue operands of the staged convolution (AUX: default kernel
-// only), padded outputs, the stem by rows; 0 = the separate passes / per-voxel stem they replaced (the same bits: the tests compare)
-tune_int g_rams_epi_fuse{1};
+// debug key 24: 1 = the round-4 fusions and kernels that keep every bit -- epilogue operands of the staged convolution (AUX: default
+// kernel only), padded outputs, the stem by rows; 0 = the separate passes / per-voxel stem they replaced (the tests compare);
+// 2 (default) = also the inference gate computed ahead of the second convolution (gate_pre_kernel: equal up to the rounding of a mean)
+tune_int g_rams_epi_fuse{2};
+tune_int g_rams_pregate_min_vox{600000};   // debug key 26: fewest voxels (batch x image) an attention block has for the gate-ahead form
 // the stem launch: rows kernel for the depths the network uses, the per-voxel kernel otherwise (a, w, bias 16-byte aligned)
 static void launch_stem(float* y, const float* x, const float* w, const float* bias, int B, int D1, int D2, int D3, unsigned* amax,
                         float* y2, hipStream_t st) {
@@ -741,12 +905,14 @@ extern unsigned long long* g_stamps;   // diagnostic builds (-DR3_STAMPS): inr_d
 static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const float* bias, float* chan_slab,
                          const unsigned* x_amax, const unsigned* w_amax, unsigned* y_amax, int B, int D1, int D2, int D3,
                          int pad, int cout, int y_cstride, int relu, int* nslab, hipStream_t st, long long slab_cap = -1,
-                         const float* aux = nullptr, int aux_mode = 0, int y_pad = 0) {
+                         const float* aux = nullptr, int aux_mode = 0, int y_pad = 0, const float* gate = nullptr) {
     INR_REQUIRE(aux_mode == 0 || (aux && rams_lds_aux_ok()), INR_E_INVALID, "RAMS convolution: epilogue operand without the default kernel");
     INR_REQUIRE(y_pad == 0 || (aux_mode == 0 && g_rams_lds_waves == 42), INR_E_INVALID, "RAMS convolution: padded output without the default kernel");
     Conv3dLdsParams p{};
     p.aux = aux;
+    p.gate = gate;
     p.y_pad = y_pad;
+    INR_REQUIRE(aux_mode != 4 || gate, INR_E_INVALID, "RAMS convolution: the gated form needs its gate");
     p.x = x; p.y = y; p.planes = planes; p.bias = bias; p.chan_slab = chan_slab;
     p.x_amax = x_amax; p.w_amax = w_amax; p.y_amax = y_amax;
     p.B = B; p.D1 = D1; p.D2 = D2; p.D3 = D3;
@@ -772,6 +938,7 @@ static int conv3d_h3_lds(const float* x, float* y, const _Float16* planes, const
         R3L_SLAB_GUARD(blocks * 4);
         if (aux_mode == 1) hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true, 1>), dim3(blocks, B), dim3(256), 0, st, p);
         else if (aux_mode == 2) hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true, 2>), dim3(blocks, B), dim3(256), 0, st, p);
+        else if (aux_mode == 4) hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true, 4>), dim3(blocks, B), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv3d_c32_lds_kernel<4, 2, true>), dim3(blocks, B), dim3(256), 0, st, p);
     } else if (two_pass) {
         if (nslab) *nslab = blocks * 8;
@@ -1132,7 +1299,8 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
     // add (nullable): the staged kernel adds this tensor to its output in the epilogue (rams_h3.inc, AUX 1); *added says whether it did
     auto conv3d = [&](const float* xin, float* yout, const float* w, const float* bias, float* chan, const unsigned* xs,
                       unsigned* ys, int D1, int D2, int D3, int pad, int cout, int cstride, int relu, int wpb,
-                      const float* add = nullptr, bool* added = nullptr, bool* padded = nullptr) -> int {
+                      const float* add = nullptr, bool* added = nullptr, bool* padded = nullptr, const float* gate_of_add = nullptr) -> int {
+        // gate_of_add (with add): y = conv * gate + add instead of conv + add (AUX 4)
         // padded (nullable): the caller would like the output written as the interior of a reflect-padded image (y_pad); *padded: done
         const int k = conv_no++;
         last_nslab = wpb;
@@ -1144,8 +1312,8 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
             if (added) *added = with_add;
             if (padded) *padded = with_pad;
             return conv3d_h3_lds(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3,
-                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap, with_add ? add : nullptr, with_add ? 1 : 0,
-                                 with_pad ? 1 : 0);
+                                 pad, cout, cstride, relu, &last_nslab, st, slab_cap, with_add ? add : nullptr,
+                                 with_add ? (gate_of_add ? 4 : 1) : 0, with_pad ? 1 : 0, with_add ? gate_of_add : nullptr);
         }
         if (h3)
             return conv3d_h3(xin, yout, planes + (long long)k * R3_LAYER_HALVES, bias, chan, xs, slots + k, ys, B, D1, D2, D3, pad,
@@ -1163,6 +1331,26 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         const int ovox = D1 * D2 * D3;
         const int wpb = rams_waves_per_b(B, ovox);
         unsigned* mid = h3 ? new_slot() : nullptr;
+        // The gate from the FIRST convolution's output (gate_pre_kernel above), scale + residual in the second one's epilogue: needs
+        // the staged kernel with its epilogue operand for both convolutions and three indices per axis (debug key 24 = 2, default)
+        // -- and enough voxels: the two small kernels in front of the second convolution cost ~33 us + 1.1 us per stack against
+        // 9 us + 10.6 us per stack of the gate and scale passes they replace (128 x 128 x 9 stacks; batch 1: 1.70 against 1.46 ms)
+        if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3) && rams_lds_aux_ok() && g_rams_epi_fuse >= 2 && D1 >= 3 && D2 >= 3 && D3 >= 3 &&
+            (long long)B * ovox >= g_rams_pregate_min_vox) {
+            if (int rc = conv3d(io, bufB, w1, b1, slab, io_slot, mid, D1, D2, D3, 1, RC, RC, 1, wpb)) return rc;   // slab: sums of r1
+            const int nslab_r1 = last_nslab;
+            hipLaunchKernelGGL(rams_class_sums_kernel, dim3(RCLS_NB, B), dim3(256), 0, st, bufC, bufB, D1, D2, D3);
+            INR_LAUNCH_CHECK();
+            hipLaunchKernelGGL(gate_pre_kernel, dim3(B), dim3(1024), 0, st, gate, slab, nslab_r1, bufC, w2, b2, 1.0f / (float)ovox, wsq,
+                               bsq, wex, bex, Cr);
+            INR_LAUNCH_CHECK();
+            unsigned* out_slot = new_slot();
+            bool added = false;
+            if (int rc = conv3d(bufB, io, w2, b2, nullptr, mid, out_slot, D1, D2, D3, 1, RC, RC, 0, wpb, io, &added, nullptr, gate)) return rc;
+            INR_REQUIRE(added, INR_E_INVALID, "rams: the gated convolution epilogue was refused");
+            io_slot = out_slot;
+            return 0;
+        }
         if (int rc = conv3d(io, bufB, w1, b1, nullptr, io_slot, mid, D1, D2, D3, 1, RC, RC, 1, wpb)) return rc;
         if (int rc = conv3d(bufB, bufC, w2, b2, slab, mid, nullptr, D1, D2, D3, 1, RC, RC, 0, wpb)) return rc;
         hipLaunchKernelGGL(gate_kernel, dim3(B), dim3(1024), 0, st, gate, slab, last_nslab, 1.0f / (float)ovox, wsq, bsq, wex,

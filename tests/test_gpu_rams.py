@@ -92,6 +92,22 @@ def test_forward_matches_oracle(B, H, W, conv_mode):
     assert pt.min() >= 0 and pt.max() <= 65536
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 24, 20), (1, 13, 31)])
+def test_gate_ahead_form_matches_oracle(B, H, W):
+    """Inference with the gate of every attention block formed AHEAD of its second convolution (class sums of the first one's
+    output; the second applies gate and residual in its epilogue) -- the default from four 128 x 128 stacks on (debug key 26), here
+    forced at test sizes, border and interior patches, odd extents -- against the same restatement and tolerances as the other form."""
+    from mri_super_resolution_amd._lib import lib
+    params = R.init_rams_params(seed=1, perturb_g=True)
+    model = rams.RAMS(3, 32, 3, 9, 8, 12, params=params)
+    x = (np.random.default_rng(B).random((B, H, W, 9)) * 20000).astype(np.float32)
+    want = R.rams_forward(params, x)
+    lib().inr_debug_set(26, 0)
+    got = model(x).cpu().numpy()
+    assert O.rel_l2(got, want) < 1e-5
+    assert O.rel_l2((got - R.MEAN) / R.STD, (want - R.MEAN) / R.STD) < 5e-5
+
+
 @pytest.mark.parametrize("scale", [2, 4])
 def test_scale_other_than_three(scale):
     """``scale`` is plumbed through RamsDesc, the head convolutions (scale^2 output channels) and the pixel shuffle.  The
@@ -272,15 +288,21 @@ def test_long_skip_in_the_convolution_epilogue_is_bit_identical():
     model = rams.RAMS(3, 32, 3, 9, 8, 12, params=R.init_rams_params(seed=4, perturb_g=True))
     rng = np.random.default_rng(2)
     try:
+        lib().inr_debug_set(26, 0)                          # (the gate-ahead form at these small sizes too)
         for shape in ((3, 40, 36, 9), (1, 64, 64, 9)):
             x = torch.from_numpy((rng.random(shape) * 30000 + 500).astype(np.float32)).cuda()
             out = {}
-            for key in (1, 0):
+            for key in (1, 0, 2):
                 lib().inr_debug_set(24, key)
                 out[key] = model(x).clone()
             assert torch.equal(out[0], out[1]) and float(out[1].abs().max()) > 0
+            # key 24 = 2 (default): the gate of every attention block from the class sums of its FIRST convolution's output, applied in
+            # the second one's epilogue -- the same mean in exact arithmetic, another order of rounding
+            a, b = out[2].cpu().numpy(), out[1].cpu().numpy()
+            assert not np.array_equal(a, b) and O.rel_l2(a, b) < 1e-6 and O.rel_l2((a - R.MEAN) / R.STD, (b - R.MEAN) / R.STD) < 2e-6   # (observed 2.3e-7 / 3.0e-7; either form is 6e-7 from the oracle)
     finally:
-        lib().inr_debug_set(24, 1)
+        lib().inr_debug_set(24, 2)
+        lib().inr_debug_set(26, 600000)
 
 
 def test_epilogue_fused_backward_is_bit_identical():
@@ -298,7 +320,7 @@ def test_epilogue_fused_backward_is_bit_identical():
             loss, _ = trainer.loss_and_grads(x, hr, mask, want_prediction=True)
             got[key] = (loss.cpu().numpy().copy(), {k: np.array(v, copy=True) for k, v in trainer.named_gradients().items()})
     finally:
-        lib().inr_debug_set(24, 1)
+        lib().inr_debug_set(24, 2)
     assert np.array_equal(got[0][0], got[1][0])
     for k in got[0][1]:
         assert np.array_equal(got[0][1][k], got[1][1][k]), k

@@ -9,11 +9,11 @@ model = rams.RAMS(seed=0)
 for B, reps in ((25, 6), (1, 40)):
     xt = torch.from_numpy((np.random.default_rng(0).random((B, 128, 128, 9)) * 60000).astype(np.float32)).cuda()
     for rnd in range(3):
-        for key in (1, 0):
+        for key in (2, 1, 0):
             lib().inr_debug_set(24, key)
             model(xt); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps): model(xt)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
             print(f"batch {B} round {rnd} key24={key}: {dt * 1e3:.3f} ms, {265.0 * B / dt / 1e3:.1f} TFLOP/s", flush=True)
-lib().inr_debug_set(24, 1)
+lib().inr_debug_set(24, 2)

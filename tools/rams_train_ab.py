@@ -22,4 +22,4 @@ for rnd in range(3):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 10
         print(f"round {rnd} key24={key}: {dt * 1e3:.3f} ms per step, {3 * fwd / dt / 1e12:.1f} TFLOP/s", flush=True)
-lib().inr_debug_set(24, 1)
+lib().inr_debug_set(24, 2)
