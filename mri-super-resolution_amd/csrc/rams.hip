@@ -1336,7 +1336,7 @@ int rams_forward_impl(const inr_rams_desc_t* d, const float* params, const float
         // -- and enough voxels: the two small kernels in front of the second convolution cost ~33 us + 1.1 us per stack against
         // 9 us + 10.6 us per stack of the gate and scale passes they replace (128 x 128 x 9 stacks; batch 1: 1.70 against 1.46 ms)
         if (h3 && g_rams_h3 == 2 && r3l_fits(D1, D2, D3) && rams_lds_aux_ok() && g_rams_epi_fuse >= 2 && D1 >= 3 && D2 >= 3 && D3 >= 3 &&
-            (long long)B * ovox >= g_rams_pregate_min_vox) {
+            (long long)B * ovox >= g_rams_pregate_min_vox && ovox >= RCLS_NB * 27) {      // (bufC holds the class partials: 64 x 27 x 32 floats per b)
             if (int rc = conv3d(io, bufB, w1, b1, slab, io_slot, mid, D1, D2, D3, 1, RC, RC, 1, wpb)) return rc;   // slab: sums of r1
             const int nslab_r1 = last_nslab;
             hipLaunchKernelGGL(rams_class_sums_kernel, dim3(RCLS_NB, B), dim3(256), 0, st, bufC, bufB, D1, D2, D3);
