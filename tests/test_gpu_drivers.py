@@ -78,6 +78,30 @@ def test_run_volumes_single_process():
     assert all(np.isfinite(r["final_loss"]) for r in recs)
 
 
+def test_run_volumes_concurrent_fits_keep_their_bits():
+    """``run_volumes(concurrent=k)``: whole-volume fits side by side on host threads and streams of their own -- every fit ends with
+    the loss, PSNR and SSIM it has when it runs alone (seeded draws are one critical section, kernels are per stream), the records
+    come back in the sequential order, and a fit that fails on its thread is recorded as such."""
+    rng = np.random.default_rng(5)
+    vols = [rng.random((24 + 4 * (k % 3), 20, 3)).astype(np.float32) + 0.05 for k in range(6)]
+    kw = dict(steps=40, chunk_steps=20)
+    seq = drivers.run_volumes(vols, **kw)
+    for k in (2, 3):
+        con = drivers.run_volumes(vols, concurrent=k, **kw)
+        assert [r["job"] for r in con] == [r["job"] for r in seq]
+        for a, b in zip(seq, con):
+            assert a["final_loss"] == b["final_loss"] and a["psnr_db"] == b["psnr_db"] and a["ssim_mean"] == b["ssim_mean"], (a, b)
+            assert b["status"] == drivers.FIT_OK
+
+    def flaky(volume, steps, return_recon=False, **kw2):
+        if volume.shape[0] == 28:
+            raise RuntimeError("boom")
+        return drivers.fit_volume(volume, steps=steps, return_recon=return_recon, **kw2)
+
+    recs = drivers.run_volumes(vols, concurrent=2, fit_fn=flaky, requeue=False, **kw)
+    assert [r["status"] for r in recs] == [drivers.FIT_ERROR if v.shape[0] == 28 else drivers.FIT_OK for v in vols]
+
+
 def test_fit_volume_cfg2_short(golden):
     """Config 2 input (whole pat07 volume): the first steps of the 3-D fit track the CPU port (kept short: the port
     needs seconds per step at N = 114,688)."""
