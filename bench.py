@@ -364,6 +364,25 @@ def small_net_leg(steps=2000, side=60, n_acq=4):
             "us_per_optimizer_step": dt * 1e6, "train_voxels_per_s": side * side / dt, "steps": steps}
 
 
+def small_fits_leg(n_fits=12, side=128, steps=300):
+    """Many slice-sized fits on one GPU (config-1 shape: 128 x 128 slice -> 4,096 training rows): `drivers.run_volumes` one at a time
+    and four side by side on streams of their own (every fit bit-identical to its solitary run); fit + x2 re-sampling, no metrics."""
+    from mri_super_resolution_amd import drivers
+    rng = np.random.default_rng(3)
+    vols = [rng.random((side, side)).astype(np.float32) + 0.05 for _ in range(n_fits)]
+    drivers.run_volumes(vols[:2], steps=10, evaluate=False)
+    out = {"config": f"{n_fits} fits of a {side} x {side} slice ({side * side // 4} rows each), {steps} steps + re-sampling", "fits": n_fits}
+    for k in (1, 4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        recs = drivers.run_volumes(vols, steps=steps, concurrent=k, evaluate=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"concurrent_{k}"] = {"seconds": dt, "coordinate_steps_per_s": sum(r["n_coords"] for r in recs) * steps / dt}
+    out["speedup"] = out["concurrent_1"]["seconds"] / out["concurrent_4"]["seconds"]
+    return out
+
+
 def cfg5_leg(steps=4):
     """Config 5 (superresHybrid.py:79-125 on a synthetic 256^3 hybrid volume): FOUR echo-time fits, each LR 128x128x256 =
     4,194,304 rows, Siren(256,512,3,1), targets stored in fp16 (as BASELINE config 5 says) and widened on the device per
@@ -674,6 +693,7 @@ def main():
         out["quality"] = cfg1_quality(inr)
         out["rams"] = rams_leg()
         out["small_net"] = small_net_leg()
+        out["small_fits_side_by_side"] = small_fits_leg()
         out["cfg2_real_volume"] = cfg2_leg()
         if not args.no_cfg4:
             out["cfg4_eleven_patients"] = cfg4_leg()
