@@ -85,3 +85,16 @@ def test_run_volumes_marks_failures_and_requeues_a_failed_ranks_fits_world_2_glo
     assert by[2]["status"] == drivers.FIT_RESEEDED and by[2]["reseeds"] == 1.0 and by[2]["final_loss"] == pytest.approx(1e-5)
     assert by[1]["status"] == drivers.FIT_FAILED and by[1]["final_loss"] != by[1]["final_loss"]      # kept and marked, not re-queued
     assert by[4]["status"] == drivers.FIT_OK and by[4]["requeued"] == 0.0
+
+
+def test_concurrent_is_sequential_without_a_gpu():
+    """`run_volumes(concurrent=k)` needs streams: on a host without a GPU the fits run one after the other, same records."""
+    from mri_super_resolution_amd import drivers
+    vols = [np.full((4, 4), float(k + 1), np.float32) for k in range(3)]
+
+    def fake(volume, steps, return_recon=False, **kw):
+        return {"n_coords": float(volume.size), "t_fit": 0.0, "t_recon": 0.0, "final_loss": float(volume[0, 0]), "status": drivers.FIT_OK}
+
+    a = drivers.run_volumes(vols, steps=1, fit_fn=fake)
+    b = drivers.run_volumes(vols, steps=1, fit_fn=fake, concurrent=3)
+    assert [r["final_loss"] for r in a] == [r["final_loss"] for r in b] == [1.0, 2.0, 3.0]
