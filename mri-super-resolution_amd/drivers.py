@@ -470,7 +470,10 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
             if not res.get("partner"):
                 record(job, res)
     whole = list(plan["whole"][rank])
-    if int(concurrent) > 1 and len(whole) > 1 and torch.cuda.is_available():
+    # (networks small enough for the persistent cooperative kernel -- grid barriers over co-resident blocks: siren_small.hip -- are
+    #  never run side by side: two such launches could each hold part of the chip and wait for the rest)
+    cooperative = fit_kwargs.get("hidden_features", 512) in (32, 64) and 2 * fit_kwargs.get("mapping_size", 128) <= 32
+    if int(concurrent) > 1 and len(whole) > 1 and torch.cuda.is_available() and not cooperative:
         from concurrent.futures import ThreadPoolExecutor
         first = len(local)
         tls = threading.local()
