@@ -464,8 +464,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a CHILD job (one process per GPU under
+        # torch.distributed.run) and relay rank 0's JSON line.  Nothing in this process has touched the GPU yet (no HIP call, no
+        # torch.cuda.is_available()), and the child is started, never exec'ed into.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     device_index = local_rank % torch.cuda.device_count()   # (a rehearsal may put several ranks on one card)
     torch.cuda.set_device(device_index)

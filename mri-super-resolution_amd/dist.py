@@ -6,10 +6,24 @@ tests).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def force_collectives() -> bool:
+    """Test hook.  A group of ONE rank needs no exchange, so every collective of this package is skipped when the group's
+    size is 1.  With ``INR_FORCE_COLLECTIVES=1`` in the environment and an initialised process group they are issued anyway (a sum /
+    broadcast / gather over one rank is the identity): this is how the RCCL branches -- the library's launches and RCCL's
+    collective ordered on the current HIP stream -- execute on a one-GPU box (``tests/test_gpu_nccl.py``)."""
+    return os.environ.get("INR_FORCE_COLLECTIVES", "") == "1" and dist.is_available() and dist.is_initialized()
+
+
+def is_shared(group_size: int) -> bool:
+    """Whether a group of ``group_size`` ranks exchanges anything (see ``force_collectives``)."""
+    return group_size > 1 or force_collectives()
 
 
 def partition_fits(costs: Sequence[float], world_size: int) -> List[List[int]]:
@@ -187,7 +201,8 @@ def rank_group(ranks: Sequence[int]):
     ``run_volumes`` per batch) must not make new ones each time.  Every rank must ask for the same groups in the same order."""
     ranks = tuple(int(r) for r in ranks)
     if len(ranks) <= 1:
-        return None
+        # (test hook: on a one-rank job with INR_FORCE_COLLECTIVES the single rank is its own "group", so that the shared-fit path runs)
+        return dist.group.WORLD if force_collectives() and dist.get_world_size() == 1 else None
     # keyed on the IDENTITY of the default group: after destroy_process_group + a new init (tests, notebooks) the old handles
     # point into a dead group, and a cache hit on some ranks only would skip the collective new_group on those ranks
     world = dist.group.WORLD
@@ -213,7 +228,7 @@ def gather_records(record: Dict[str, float]) -> List[Dict[str, float]]:
     rank.  Implemented as ONE fixed-size tensor ``all_gather`` (float64 x len(record)): on the ``nccl``
     backend this is the RCCL collective, on ``gloo`` a CPU tensor is used."""
     keys = sorted(record)
-    if _world() == 1:
+    if not is_shared(_world()):
         return [dict(record)]
     backend = dist.get_backend()
     device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
@@ -235,7 +250,7 @@ def gather_job_records(local: List[Dict[str, float]], keys: Sequence[str], max_j
     for j, rec in enumerate(local):
         for c, k in enumerate(keys):
             buf[j * width + c] = float(rec[k])
-    if _world() == 1:
+    if not is_shared(_world()):
         rows = [buf]
     else:
         backend = dist.get_backend()

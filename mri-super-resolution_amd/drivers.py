@@ -77,7 +77,7 @@ def fit_volume(volume: np.ndarray, steps: int = 2500, *, seed: Optional[int] = 0
     while True:
         s = None if seed is None else seed + 7919 * attempt
         res = _fit_volume_once(volume, steps, seed=s, group=group, _poison=bool(_fault and _fault(attempt) == "nan"), **kwargs)
-        shared = group is not None and torch.distributed.get_world_size(group) > 1
+        shared = group is not None and inr_dist.is_shared(torch.distributed.get_world_size(group))
         health = fit_health(res.get("final_loss"), None if shared else res.get("_recon_probe"))
         res.pop("_recon_probe", None)
         res["health"], res["reseeds"] = health, attempt
@@ -112,16 +112,17 @@ def _fit_volume_once(volume: np.ndarray, steps: int = 2500, hidden_features: int
     test_shape = tuple(2 * s if a < upscale_axes else s for a, s in enumerate(hr_shape))
     # (seeding torch's global generator and drawing the weights from it is one critical section: `run_volumes(concurrent=k)` runs
     #  several fits of this process at once, and each must get the weights its seed gives a fit that runs alone)
+    shared = group is not None and inr_dist.is_shared(torch.distributed.get_world_size(group))
     _INIT_LOCK.acquire()
     try:
         if seed is not None:
             torch.manual_seed(seed)
         B = torch.from_numpy(fourier_matrix(vol.ndim, mapping_size, ff_scale, seed)).cuda()
-        if not (group is not None and torch.distributed.get_world_size(group) > 1):
+        if not shared:
             model = Siren(2 * mapping_size, hidden_features, hidden_layers, 1).cuda()
     finally:
         _INIT_LOCK.release()
-    if group is not None and torch.distributed.get_world_size(group) > 1:
+    if shared:
         # one fit, several ranks: everybody uses the first rank's Fourier matrix (the weights follow in the fitter)
         src = torch.distributed.get_global_rank(group, 0)
         if torch.distributed.get_backend(group) == "nccl":
@@ -140,7 +141,7 @@ def _fit_volume_once(volume: np.ndarray, steps: int = 2500, hidden_features: int
     g_rank = torch.distributed.get_rank(group) if group is not None else 0
     torch.cuda.current_stream().synchronize()      # (this fit's stream: fits may run side by side)
     t0 = time.perf_counter()
-    if g_size > 1:
+    if shared:
         n_rows = model_input.shape[0]
         lo, hi = n_rows * g_rank // g_size, n_rows * (g_rank + 1) // g_size
         model_input, pixels = model_input[lo:hi].contiguous(), pixels[lo:hi].contiguous()
@@ -160,7 +161,8 @@ def _fit_volume_once(volume: np.ndarray, steps: int = 2500, hidden_features: int
     fitter.release_workspace()
     if g_rank != 0:      # a partner of a sharded fit: the group's first rank owns re-sampling and evaluation
         return {"n_coords": int(lr_vol.size), "steps": int(steps), "t_fit": t_fit, "t_recon": 0.0,
-                "final_loss": float(torch.cat(losses)[-1]) if steps else None, "model": model, "B": B, "partner": True}
+                "final_loss": float(torch.cat(losses)[-1]) if steps else None,
+                "first_loss": float(losses[0][0]) if steps else None, "model": model, "B": B, "partner": True}
     t0 = time.perf_counter()
     recon = reconstruct(model, test_shape, B)                            # superresDWI.py:125-126,161
     torch.cuda.current_stream().synchronize()
@@ -169,7 +171,7 @@ def _fit_volume_once(volume: np.ndarray, steps: int = 2500, hidden_features: int
         "n_coords": int(lr_vol.size), "steps": int(steps), "t_fit": t_fit, "t_recon": t_rec,
         "train_voxels_per_s": lr_vol.size * steps / t_fit, "recon_voxels_per_s": recon.numel() / t_rec,
         "e2e_voxels_per_s": recon.numel() / (t_fit + t_rec), "final_loss": float(torch.cat(losses)[-1]) if steps else None,
-        "test_shape": test_shape, "scale_back": vmax,
+        "first_loss": float(losses[0][0]) if steps else None, "test_shape": test_shape, "scale_back": vmax,
     }
     if evaluate and downsample:
         hr = torch.from_numpy(vol).cuda()
@@ -296,7 +298,7 @@ def fit_slice_ensemble(acquisitions: Sequence[np.ndarray], weights: Optional[Seq
 
 
 RECORD_KEYS = ("job", "n_coords", "steps", "t_fit", "t_recon", "psnr_db", "ssim_mean", "final_loss", "status", "reseeds", "rank",
-               "requeued")
+               "requeued", "first_loss")      # first_loss: the loss of the step-0 weights (a fit's own yardstick for "it went down")
 
 
 def hybrid_te_groups(world_size: int) -> List[List[int]]:
@@ -345,7 +347,7 @@ def fit_hybrid(hybrid_raw: np.ndarray, roi: Optional[Sequence[int]] = None, slic
     losses = []
     if target_dtype is not None:
         norm = norm.astype(target_dtype)
-    spread = distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    spread = distributed and torch.distributed.is_initialized() and inr_dist.is_shared(torch.distributed.get_world_size())
     rank = torch.distributed.get_rank() if spread else 0
     te_ranks = hybrid_te_groups(torch.distributed.get_world_size()) if spread else [[0]] * 4
     # (group creation is collective over the default group: every rank asks for every group, in the same order; cached)
@@ -416,8 +418,16 @@ def plan_volumes(volumes: Sequence[np.ndarray], steps: int, world: int, allow_sh
     return plan
 
 
+class FitError(RuntimeError):
+    """``run_volumes``: fits that raised on their rank and that no surviving rank could take over (``.records`` = all records)."""
+
+    def __init__(self, message, records):
+        super().__init__(message)
+        self.records = records
+
+
 def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True, stats: Optional[dict] = None,
-                fit_fn=None, requeue: bool = True, concurrent: int = 1, **fit_kwargs) -> List[Dict[str, float]]:
+                fit_fn=None, requeue: bool = True, concurrent: int = 1, errors: str = "raise", **fit_kwargs) -> List[Dict[str, float]]:
     """Fits every volume once over the ranks of the current process group and returns the gathered per-fit metric
     records on every rank (one RCCL all_gather).  Schedule: ``plan_volumes`` / ``dist.plan_fits`` -- the volumes that do not
     fill a whole round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
@@ -429,7 +439,12 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
     after the re-seeds: kept, marked, metrics as measured) or FIT_ERROR (the fit RAISED on its rank -- a device error, an
     allocation failure).  With ``requeue`` the whole-volume fits that ended in FIT_ERROR are dealt, longest first, to the ranks
     that reported no error (the survivors; every rank derives the same assignment from the gathered records), run there and
-    gathered once more; ``requeued`` = 1 marks their records.  A fit shared by a rank group is not re-queued: a member that
+    gathered once more; ``requeued`` = 1 marks their records.  Only RUNTIME failures are turned into records (``RuntimeError`` and
+    its subclasses: device errors, ``InrHipError``, ``torch.cuda.OutOfMemoryError``); a programming error (``TypeError`` from a bad
+    keyword, ``ValueError``, ...) propagates at once, as does any failure when this process is the whole job (world 1: nobody could
+    take the fit over, the first exception is re-raised after the loop).  ``errors="raise"`` (default): records still FIT_ERROR after
+    the re-queue raise ``FitError`` on every rank (all ranks hold the same gathered records, so all raise); ``errors="record"`` returns
+    them, NaN metrics and all.  A fit shared by a rank group is not re-queued: a member that
     raises mid-fit leaves its partners in the gradient all-reduce, which this layer cannot repair -- the exception propagates.
     ``fit_fn(volume, steps=..., return_recon=False, **fit_kwargs)`` replaces ``fit_volume`` (tests of the scheduling itself).
 
@@ -450,14 +465,20 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
                       "t_recon": res["t_recon"], "psnr_db": res.get("psnr_db", nan),
                       "ssim_mean": res.get("ssim_mean", nan),
                       "final_loss": nan if res.get("final_loss") is None else res["final_loss"],
+                      "first_loss": nan if res.get("first_loss") is None else res["first_loss"],
                       "status": float(res.get("status", FIT_OK)), "reseeds": float(res.get("reseeds", 0)), "rank": float(rank),
                       "requeued": requeued})
+
+    if errors not in ("raise", "record"):
+        raise ValueError(f"errors must be 'raise' or 'record', got {errors!r}")
+    raised = []
 
     def run_whole(job, requeued=0.0):
         try:
             record(job, fit(volumes[job], steps=steps, return_recon=False, **fit_kwargs), requeued)
-        except Exception as e:  # noqa: BLE001 -- the record says so; the survivors take the job over
+        except RuntimeError as e:      # device / library / allocation failures; the record says so, the survivors take the job over
             import sys
+            raised.append(e)
             print(f"[run_volumes] rank {rank}: fit of volume {job} raised {type(e).__name__}: {e}", file=sys.stderr)
             record(job, {"n_coords": float(np.asarray(volumes[job]).size), "t_fit": nan, "t_recon": nan, "final_loss": nan,
                          "status": FIT_ERROR}, requeued)
@@ -519,4 +540,11 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
             records = [redone.get(int(r["job"]), r) if r["status"] == FIT_ERROR else r for r in records]
             if stats is not None:
                 stats["requeued"] = sorted(redone)
-    return sorted(records, key=lambda r: r["job"])
+    records = sorted(records, key=lambda r: r["job"])
+    still = [int(r["job"]) for r in records if r["status"] == FIT_ERROR]
+    if still and errors == "raise":
+        if world == 1 and raised:
+            raise raised[0]                                # single process: the caller sees the exception itself
+        raise FitError(f"run_volumes: fits of volumes {still} raised and no rank could take them over "
+                       f"(errors='record' returns the NaN records instead)", records)
+    return records

@@ -503,7 +503,8 @@ class ShardedSirenFitter(SirenFitter):
 
     def _all_reduce(self, t):
         import torch.distributed as dist
-        if self._world() == 1:
+        from .dist import is_shared
+        if not is_shared(self._world()):
             return
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -524,7 +525,8 @@ class ShardedSirenFitter(SirenFitter):
 
     def sync_replicas(self):
         """Every rank takes the weights, Adam moments and step count of the group's first rank."""
-        if self._world() == 1:
+        from .dist import is_shared
+        if not is_shared(self._world()):
             return
         count = torch.tensor([float(self.step_count)], dtype=torch.float64, device=self.flat.device)
         for t in (self.flat, self.m, self.v, count):

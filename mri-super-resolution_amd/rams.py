@@ -107,6 +107,29 @@ class RAMS:
     def invalidate(self):
         self._packed = None
 
+    # ---- weights on disk (the shipped TensorFlow checkpoints are incomplete -- the *.data-00001-of-00002 shard is stripped -- and
+    #      there is no TensorFlow here to read one: weights travel as an .npz of the reference's variables, `<layer>/v|g|b`) -------------
+    def save_weights(self, path):
+        np.savez(path, **{k: np.asarray(v, np.float32) for k, v in self.params.items()})
+        return path
+
+    def load_weights(self, path):
+        """Takes every ``<layer>/v``, ``<layer>/g``, ``<layer>/b`` of this architecture from an ``.npz`` (shapes checked)."""
+        with np.load(path, allow_pickle=False) as z:
+            new = {}
+            for name, ks, cin, cout in self.specs:
+                for suffix, shape in (("v", tuple(ks) + (cin, cout)), ("g", (cout,)), ("b", (cout,))):
+                    key = f"{name}/{suffix}"
+                    if key not in z.files:
+                        raise KeyError(f"{path}: no array '{key}' (expected {len(self.specs) * 3} arrays named <layer>/v|g|b)")
+                    a = np.asarray(z[key], np.float32)
+                    if a.shape != shape:
+                        raise ValueError(f"{path}: '{key}' has shape {a.shape}, this network needs {shape}")
+                    new[key] = a
+        self.params = new
+        self.invalidate()
+        return self
+
     # ---- forward ---------------------------------------------------------------------------------------------
     def forward(self, x, clip_round=False):
         """x: ``[B, H, W, channels]`` (numpy or tensor, any real dtype; cast to fp32 like prediction.py:78).

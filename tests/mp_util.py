@@ -24,7 +24,12 @@ def _entry(rank, world, port, q, fn, args, backend):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        kw = {}
+        if backend == "nccl":               # RCCL: one device per rank, bound before the first collective
+            import torch
+            torch.cuda.set_device(rank)
+            kw["device_id"] = torch.device("cuda", rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120), **kw)
         try:
             q.put(("ok", rank, fn(rank, world, *args)))
         finally:

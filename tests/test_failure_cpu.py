@@ -98,3 +98,49 @@ def test_concurrent_is_sequential_without_a_gpu():
     a = drivers.run_volumes(vols, steps=1, fit_fn=fake)
     b = drivers.run_volumes(vols, steps=1, fit_fn=fake, concurrent=3)
     assert [r["final_loss"] for r in a] == [r["final_loss"] for r in b] == [1.0, 2.0, 3.0]
+
+
+def test_run_volumes_single_process_errors_are_not_swallowed():
+    """with one process nobody can take a failed fit over -- the runtime error reaches the caller (after the other
+    fits ran), a programming error propagates at once, and `errors="record"` is the explicit way to get NaN records instead."""
+    vols = [np.full((4, 4), float(k + 1), np.float32) for k in range(3)]
+    ran = []
+
+    def fit(volume, steps, return_recon=False, **kw):
+        ran.append(float(volume[0, 0]))
+        if volume[0, 0] == 2.0:
+            raise RuntimeError("device lost")
+        return {"n_coords": float(volume.size), "t_fit": 0.0, "t_recon": 0.0, "final_loss": 1e-5, "status": drivers.FIT_OK}
+
+    with pytest.raises(RuntimeError, match="device lost"):
+        drivers.run_volumes(vols, steps=1, fit_fn=fit)
+    assert sorted(ran) == [1.0, 2.0, 3.0]                      # the healthy fits were not abandoned
+    recs = drivers.run_volumes(vols, steps=1, fit_fn=fit, errors="record")
+    assert [r["status"] for r in recs] == [drivers.FIT_OK, drivers.FIT_ERROR, drivers.FIT_OK] and recs[1]["final_loss"] != recs[1]["final_loss"]
+
+    def typo(volume, steps, return_recon=False, **kw):
+        raise TypeError("fit_volume() got an unexpected keyword argument 'hiden_features'")
+
+    with pytest.raises(TypeError):
+        drivers.run_volumes(vols, steps=1, fit_fn=typo, errors="record")
+    with pytest.raises(ValueError):
+        drivers.run_volumes(vols, steps=1, fit_fn=fit, errors="ignore")
+
+
+def _all_fail_worker(rank, world):
+    from mri_super_resolution_amd import drivers as D
+    vols = [np.full((4, 4), float(k + 1), np.float32) for k in range(4)]
+
+    def fit(volume, steps, return_recon=False, **kw):
+        raise RuntimeError("library missing on every rank")
+
+    try:
+        D.run_volumes(vols, steps=1, allow_sharding=False, fit_fn=fit, hidden_features=64)
+    except D.FitError as e:
+        return sorted(int(r["job"]) for r in e.records if r["status"] == D.FIT_ERROR)
+    return None
+
+
+def test_run_volumes_raises_on_every_rank_when_no_rank_survives_world_2_gloo():
+    a, b = run_ranks(_all_fail_worker, 2, timeout=120)
+    assert a == b == [0, 1, 2, 3]

@@ -65,3 +65,18 @@ def test_bench_two_ranks_rehearsal_gloo():
     assert sorted([e["plan"]["gangs"][0][0]] + [j for w in e["plan"]["whole"] for j in w]) == list(range(11))
     assert e["coordinate_steps_per_s"] == pytest.approx(sum(64 * 64 * z for z in [24] * 3 + [28] * 5 + [34] * 3) * 6 / e["seconds"], rel=1e-6)
     assert 15.0 < e["psnr_db_mean"] < 45.0 and e["final_loss_max"] < 0.2
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (a driver that does not wrap it in torch.distributed.run):
+    bench.py starts the ranks itself as a child job -- before anything has touched the GPU -- and relays rank 0's line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(INR_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+                          "--no-cpu-baseline", "--no-eleven"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["value"] == pytest.approx(2 * 524288 * 2 / (d["ms_per_step"] * 2e-3), rel=1e-6)

@@ -12,6 +12,7 @@ import torch
 import mri_super_resolution_amd as inr
 from mri_super_resolution_amd import baselines, contrast, drivers, matio, ops, reports
 from mri_super_resolution_amd.scripts import master as master_script
+from mri_super_resolution_amd.scripts import rams_master as rams_master_script
 from mri_super_resolution_amd.scripts import superresDWI as dwi_script
 from oracle import inr_oracle as O
 from oracle import torch_port as P
@@ -195,6 +196,55 @@ def test_master_entry_point_writes_the_contrast_csv(tmp_path, golden):
     assert (args.total_steps, args.hidden_layers, args.hidden_features, args.ROI_begin) == (3000, 2, 64, 40)
     with pytest.raises(NotImplementedError):
         contrast.save_dicom(np.zeros((2, 2)), "x.dcm")
+
+
+def test_rams_master_entry_point_on_a_synthetic_alldata_file(tmp_path):
+    """multi-image-super-resolution/master.py:20-62 end to end: `patNN_alldata.mat` (128, 128, Z, T) + `patNN_mean_b0.mat` written
+    by matio -> x256 -> random 9-subsets through RAMS(3, 32, 3, 9, 8, 12) -> mean (384, 384) -> ADC -> .npy / .mat.  The subset
+    forwards are checked against the host restatement (oracle/rams_port.py: parity unpinned against TensorFlow), the
+    ADC against the reference's formula evaluated here."""
+    import random
+
+    from mri_super_resolution_amd import rams
+    from oracle import rams_port as R
+    rng = np.random.default_rng(8)
+    gx, gy = np.meshgrid(np.linspace(0, 1, 128), np.linspace(0, 1, 128), indexing="ij")
+    base = 60.0 + 50.0 * np.sin(5 * gx) * np.cos(4 * gy)
+    Z, T = 3, 12
+    dwi = np.stack([np.stack([base * (1 + 0.1 * z) * (1 + 0.04 * rng.standard_normal(base.shape)) for _ in range(T)], axis=-1)
+                    for z in range(Z)], axis=2).clip(1, 250).astype(np.float32)                      # [128, 128, Z, T]
+    b0 = np.stack([2.5 * base * (1 + 0.1 * z) for z in range(Z)], axis=2).astype(np.float32)
+    data_dir = tmp_path / "anon_data"
+    data_dir.mkdir()
+    matio.savemat(str(data_dir / "pat09_alldata.mat"), {"data": dwi})
+    matio.savemat(str(data_dir / "pat09_mean_b0.mat"), {"data_mean_b0": b0})
+    spec = [{"pt_id": "18-1681-09", "b": 900, "cancer_loc": [60, 70], "contralateral_loc": [60, 55], "noise": [45, 45],
+             "cancer_slice": 1, "acquisitions": [4, 4, 4]}]
+    with open(str(tmp_path / "cases.json"), "w") as fh:
+        json.dump(spec, fh)
+    params = R.init_rams_params(seed=4, perturb_g=True)
+    weights = rams.RAMS(3, 32, 3, 9, 8, 12, params=params).save_weights(str(tmp_path / "rams.npz"))
+    out = rams_master_script.main(["--out_folder", str(tmp_path / "exp"), "--out_img_folder", str(tmp_path / "img"), "--exp_name", "mi1",
+                                   "--data_dir", str(data_dir), "--cases", str(tmp_path / "cases.json"), "--weights", weights,
+                                   "--sample_size", "2", "--seed", "3"])
+    rec, = out["cases"]
+    assert rec["patient"] == "09" and rec["shape"] == [384, 384] and rec["sample_size"] == 2
+    draws = random.Random(3)
+    assert rec["subsets"] == [draws.sample(list(range(T)), 9) for _ in range(2)]                  # master.py:46 under --seed
+    mean = np.load(os.path.join(rec["out_dir"], "DWI_mean.npy"))
+    adc = np.load(os.path.join(rec["out_dir"], "ADC_mean.npy"))
+    mat = matio.loadmat(os.path.join(rec["out_dir"], "images.mat"))
+    assert mean.shape == adc.shape == (384, 384) and np.array_equal(mat["DWI_mean"], mean) and np.array_equal(mat["ADC_mean"], adc)
+    lor = dwi[:, :, 1, :][None].astype("uint16") * 256                                            # master.py:40-42
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    want = np.mean([R.predict_tensor(params, lor[:, :, :, s].astype(np.float32))[0, :, :, 0] for s in rec["subsets"]], axis=0)
+    assert np.abs(mean - want).max() <= 1.0 and float((mean != want).mean()) < 4e-2              # rounded outputs: half-integer flips only
+    b0_scaled = ndi.zoom(b0[:, :, 1].astype(np.float64), 3, order=1, mode="mirror", grid_mode=True)
+    want_adc = -np.log((mean / (b0_scaled + 1e-7)) + 1e-7) / 900 * 1000000                       # master.py:53-57
+    assert np.allclose(adc, want_adc, rtol=1e-5, atol=1e-3)
+    assert os.path.exists(os.path.join(str(tmp_path / "exp"), "mi1.json"))
+    with pytest.raises(SystemExit):                                                                  # no patient table: says so
+        rams_master_script.main(["--out_folder", str(tmp_path / "exp"), "--data_dir", str(data_dir)])
 
 
 def _hybrid_master(path, X=32, Z=3, seed=2):
