@@ -417,9 +417,8 @@ def hybrid_fit_leg(n=120 * 120 * 4):
     """(f)-1: three-compartment fit of four 120x120 slices worth of voxels (PIA.hybrid_fit, superresHybrid.py:140),
     2 % noise; next to scipy's curve_fit on 32 of the same voxels on one host core."""
     from mri_super_resolution_amd import pia
-    from oracle import pia_oracle as P
     from scipy.optimize import curve_fit
-    sig_np = P.synthetic_signals(n, 0.02, seed=5)
+    sig_np = pia.phantom_signals(n, 0.02, seed=5)
     sig = torch.from_numpy(sig_np).cuda()
     pia.hybrid_fit_device(sig[:6400])
     torch.cuda.synchronize()
@@ -427,12 +426,12 @@ def hybrid_fit_leg(n=120 * 120 * 4):
     out = pia.hybrid_fit_device(sig)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    f = lambda M, *p: P.three_compartment(np.array(p), M[0], M[1])
+    b16, te16 = pia.acquisition_table()
     t0 = time.perf_counter()
     for y in sig_np[:32]:
         try:
-            curve_fit(f, np.vstack([P.B16, P.TE16]), y, p0=list(P.P0), bounds=(list(P.LB), list(P.UB)), method="trf",
-                      maxfev=5000)
+            curve_fit(pia.three_compartment_fit, np.vstack([b16, te16]), y, p0=list(pia.P0), bounds=(list(pia.LB), list(pia.UB)),
+                      method="trf", maxfev=5000)
         except RuntimeError:
             pass
     dt_cpu = (time.perf_counter() - t0) / 32

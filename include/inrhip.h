@@ -12,22 +12,37 @@
  *  - plain C: raw DEVICE pointers, int64 sizes, scalar hyper-parameters, a hipStream_t passed as
  *    void* (0 = the null stream).  No torch types, no ownership transfer: the caller allocates every
  *    output and every workspace (size from the matching *_workspace_bytes query).
- *  - every function only ENQUEUES work on `stream` and returns without synchronising (graph-capture
- *    safe: no allocation, no host sync inside; the fused fit forks its parameter-gradient GEMMs onto one
- *    library-owned non-blocking stream per device -- created on first use -- and joins it back into
- *    `stream` by events before it returns: everything the call enqueued is ordered before whatever the
- *    caller enqueues on `stream` next).  ONE exception: when inr_siren_fit / inr_siren_fit_cycle
- *    take the persistent cooperative small-network kernel (hidden 32 / 64, <= 32 input features, one
- *    output, few thousand rows) they wait for the stream once at the end of the call to read the
- *    kernel's completion word, and return INR_E_TIMEOUT if a launch was abandoned (cooperative launches
- *    cannot be captured into a graph in any case).
- *  - threading: entry points may be called concurrently from several host threads on different streams
- *    with disjoint buffers; the library keeps no per-call state.  Process-global state is limited to
- *    (i) the event profiler behind inr_prof_*, (ii) the launch counters behind inr_launch_count and
- *    (iii) the DIAGNOSTIC switches behind inr_debug_set / inr_debug_set_ptr, which select kernel families
- *    for A/B measurements and tests.  The switches are atomics, but they are process-wide: flipping one
- *    while another thread is enqueueing changes what that thread launches next.  A production caller
- *    never touches them; a test harness restores them with inr_debug_reset().
+ *  - every function only ENQUEUES work on `stream` and returns without synchronising.  Everything a call launches goes onto
+ *    `stream` itself, in program order: the library owns NO stream and creates no events of its own for ordering (rounds 1-3
+ *    forked the parameter-gradient GEMMs onto a library-owned side stream; since round 4 they are one merged launch on
+ *    `stream`).  Consequently (a) whatever the caller enqueues on `stream` after the call is ordered behind all of its work,
+ *    (b) calls on DIFFERENT streams are not ordered against each other by the library, and (c) the calls contain no
+ *    allocation and no host synchronisation, so a sequence of them can be captured into a HIP graph.  TWO documented
+ *    exceptions to "no host sync": when inr_siren_fit / inr_siren_fit_cycle take the persistent cooperative small-network
+ *    kernel (hidden 32 / 64, <= 32 input features, one output, few thousand rows) they wait for `stream` once at the end of
+ *    the call to read the kernel's completion word, and return INR_E_TIMEOUT if a launch was abandoned (cooperative
+ *    launches cannot be captured into a graph in any case); and inr_prof_read() waits for the events it reports on.
+ *  - threading / concurrency: entry points may be called concurrently from several host threads on different streams with
+ *    DISJOINT output and workspace buffers (read-only inputs may be shared); this is what
+ *    drivers.run_volumes(concurrent=k) relies on -- k fits of one process, each on a host thread and a stream of its own,
+ *    each with its own parameter / moment / workspace buffers.  One call uses one workspace; the same workspace must not be
+ *    in use by two calls that may overlap on the device.  The cooperative small-network kernel needs its whole grid
+ *    co-resident: two such launches on different streams at the same time can each hold part of the chip and stall until the
+ *    grid barrier's poll limit reports INR_E_TIMEOUT -- run those fits one after the other (run_volumes does).
+ *    Process-global state, all of it safe to touch from several threads, none of it carrying tensor data:
+ *      (i)   the thread-local message behind inr_last_error();
+ *      (ii)  the event profiler behind inr_prof_* (a mutex; off unless enabled);
+ *      (iii) the launch counters behind inr_launch_count (atomics);
+ *      (iv)  the workspace stamps that guard INR_REUSE_* flags and the pending inr_siren_forward_train stash: 64 entries
+ *            keyed on the workspace ADDRESS (a mutex; least recently used entry replaced).  A stamp says which (n, x,
+ *            target, weight) the operand image in that workspace was built from; it cannot know that the caller freed the
+ *            workspace and received the same address again -- a caller that recycles workspace memory must not pass
+ *            INR_REUSE_* on the first call after doing so;
+ *      (v)   the per-device co-residency limits of the cooperative kernel (atomics, computed once per device);
+ *      (vi)  the DIAGNOSTIC switches behind inr_debug_set / inr_debug_set_ptr, which select kernel families for A/B
+ *            measurements and tests.  They are atomics, but process-wide: flipping one while another thread is enqueueing
+ *            changes what that thread launches next (and whether inr_siren_hp_eligible says yes).  A production caller never
+ *            touches them; a test harness restores them with inr_debug_reset().
  *  - return value: 0 = ok; negative = invalid argument (INR_E_*); positive = hipError_t.
  *    inr_last_error() returns a thread-local human-readable message for the last failure.
  *  - all tensors are dense row-major fp32.  Linear weights are [out_features][in_features] exactly as

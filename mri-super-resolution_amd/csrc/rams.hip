@@ -796,7 +796,7 @@ struct Cursor {
     const float* base;
     long long off = 0;
     const float* take(long long n) {
-        const float* p = base + off;
+        const float* p = base ? base + off : nullptr;     // (a counting walk has no base: no arithmetic on a null pointer)
         off += (n + 3) / 4 * 4;
         return p;
     }

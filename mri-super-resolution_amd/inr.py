@@ -254,6 +254,10 @@ class _TrainState:
         ws, self._free_ws = self._free_ws, None
         if ws is None or ws.numel() < need or ws.device != device:
             ws = torch.empty(need, dtype=torch.uint8, device=device)
+            # A NEW allocation may have been handed the address of a workspace a dropped graph freed (a forward without backward
+            # never gives its workspace back): the address alone would then match `_last` -- and the C side's stamp for it -- while
+            # other tensors have owned the memory in between.  The operand image is only trusted on a workspace this state kept.
+            self._last = None
         return ws
 
     def give_back(self, ws):
@@ -294,6 +298,10 @@ class _SirenHpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         st = ctx.state
+        if ctx.ws is None:
+            raise RuntimeError("the fused SIREN path runs ONE backward per forward (its stash workspace went back to the pool after the "
+                               "first); for retain_graph=True or two losses sharing one forward set "
+                               "mri_super_resolution_amd.inr.HP_AUTOGRAD = False (layer-by-layer exact-fp32 path)")
         grads = torch.empty(st.total, dtype=torch.float32, device=gy.device)      # fresh: .grad may alias what is returned here
         ops.siren_backward_train(st.desc, st.flat, grads, gy.contiguous(), ctx.ws)
         st.give_back(ctx.ws)
@@ -379,10 +387,8 @@ class Siren(nn.Module):
             return False
         if not all(p.requires_grad and p.is_cuda and p.dtype == torch.float32 for p in params):
             return False
-        ok = self.__dict__.get("_hp_ok")
-        if ok is None:
-            ok = self.__dict__["_hp_ok"] = ops.siren_hp_eligible(self.desc())
-        return ok
+        # (asked every time: eligibility also depends on the process-global diagnostic switches -- a host-only call, no device work)
+        return ops.siren_hp_eligible(self.desc())
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -57,7 +57,10 @@ class _File:
         if (self.o, self.l) != (8, 8):
             raise MatFormatError(f"{path}: {self.o}-byte offsets / {self.l}-byte lengths are not supported")
         p = at + 24 + (4 if ver == 1 else 0)
-        self.base, _free, _eof, _drv = struct.unpack_from("<4Q", buf, p)
+        _stored_base, _free, _eof, _drv = struct.unpack_from("<4Q", buf, p)
+        # libhdf5 (H5F__super_read) takes the place where it FOUND the superblock as the base of every address and overrides the
+        # stored field when the two differ (a 512-byte user block in front of a file whose stored base address is 0)
+        self.base = at
         self.root = self._symbol_entry(p + 32)
 
     # -- primitives ------------------------------------------------------------------------------------------------
@@ -329,11 +332,13 @@ def is_mat73(head: bytes) -> bool:
     return head[:10] == b"MATLAB 7.3" or head[:8] == _SIG
 
 
-def loadmat73(path: str) -> Dict[str, object]:
+def loadmat73(path: str, buf: bytes = None) -> Dict[str, object]:
     """``{name: value}`` of a MATLAB 7.3 (HDF5) file: what ``mat73.loadmat`` gives the reference (``superresDWI.py:43``), with cells
-    as object arrays (``value[b][te]`` works as there) instead of nested lists."""
-    with open(path, "rb") as fh:
-        buf = fh.read()
+    as object arrays (``value[b][te]`` works as there) instead of nested lists.  ``buf``: the file's bytes when the caller has
+    already read them (``matio.loadmat`` has)."""
+    if buf is None:
+        with open(path, "rb") as fh:
+            buf = fh.read()
     try:
         return _load(buf, path)
     except (struct.error, IndexError, KeyError, zlib.error, UnicodeDecodeError, OverflowError) as e:

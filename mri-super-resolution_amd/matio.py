@@ -99,7 +99,7 @@ def loadmat(path: str) -> Dict[str, np.ndarray]:
     if buf[:8] == b"\x89HDF\r\n\x1a\n" or buf[:10] == b"MATLAB 7.3":
         mod = _mat73_module()                     # the reference's fallback: `except NotImplementedError: mat73.loadmat(...)`
         try:
-            return mod.loadmat73(path)
+            return mod.loadmat73(path, buf)
         except mod.MatFormatError as e:           # (this file loaded on its own, outside the package: another class object)
             if isinstance(e, MatFormatError):
                 raise

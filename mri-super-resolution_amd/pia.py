@@ -14,6 +14,28 @@ from . import ops
 from ._lib import check, lib
 
 P0 = (0.55, 1.3, 2.8, 50.0, 70.0, 750.0, 0.3, 0.4)     # PIA.py:269
+LB = (0.3, 0.7, 2.7, 20.0, 40.0, 500.0, 0.0, 0.0)      # PIA.py:271
+UB = (0.7, 1.7, 3.0, 70.0, 100.0, 1000.0, 1.0, 1.0)    # PIA.py:272
+BVALS = (0.0, 150.0, 1000.0, 1500.0)                   # PIA.py:254
+NORM_TE = (0.0, 13.0, 93.0, 143.0)                     # PIA.py:255
+
+
+def acquisition_table():
+    """``xdata`` of PIA.py:263-264 (``meshgrid(normTE, bvals)``: b is the slow index): ``(b [16], TE [16])``."""
+    return np.repeat(np.asarray(BVALS), 4), np.tile(np.asarray(NORM_TE), 4)
+
+
+def phantom_signals(n, noise=0.02, seed=0):
+    """Seeded three-compartment signals ``[n, 16]`` in the reference's units, for benchmarks and demos: parameters uniform inside
+    the fit bounds, volume fractions normalised, additive Gaussian noise (the recipe of ``PIA.get_batch``, PIA.py:171-213, with
+    numpy's own generator)."""
+    rng = np.random.default_rng(seed)
+    p = np.column_stack([rng.uniform(LB[k], UB[k], n) for k in range(6)])
+    vol = rng.uniform(0, 1, (n, 3))
+    vol /= vol.sum(axis=1, keepdims=True)
+    b, te = acquisition_table()
+    sig = three_compartment_fit((b[None, :], te[None, :]), *(p[:, k:k + 1] for k in range(6)), vol[:, 0:1], vol[:, 1:2]) / 1000.0
+    return 1000.0 * (sig + rng.normal(0, noise, sig.shape))
 
 
 def three_compartment_fit(M, D_ep, D_st, D_lu, T2_ep, T2_st, T2_lu, V_ep, V_st):

@@ -17,6 +17,8 @@ def _pad8(b: bytes) -> bytes:
 
 
 class Writer:
+    stored_base = BASE          # the superblock's "base address" field; 0 = the other form libhdf5 accepts behind a user block
+
     def __init__(self):
         head = b"MATLAB 7.3 MAT-file, Platform: GLNXA64, Created on: Mon Oct  5 00:00:00 2026 HDF5 schema 1.00 ."
         self.buf = bytearray(head.ljust(116) + b"\0" * 8 + struct.pack("<H", 0x0200) + b"IM")
@@ -202,7 +204,7 @@ class Writer:
         root = self.group(members)
         btree, heap = self._last_group
         sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBxBBBxHHI", 0, 0, 0, 0, 8, 8, 4, 16, 0)
-        sb += struct.pack("<QQQQ", BASE, UNDEF, len(self.buf) - BASE, UNDEF)
+        sb += struct.pack("<QQQQ", self.stored_base, UNDEF, len(self.buf) - BASE, UNDEF)
         sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", btree, heap)
         self.buf[BASE:BASE + len(sb)] = sb
         return bytes(self.buf)

@@ -204,3 +204,64 @@ def test_small_and_ineligible_shapes_keep_working():
     ref(x.cpu()).sum().backward()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         assert O.rel_l2(host(p.grad), q.grad.numpy()) < 5e-5, n
+
+
+def test_dropped_graph_does_not_leave_a_stale_operand_image(golden):
+    """a training-mode forward whose graph is dropped WITHOUT a backward never gives its stash workspace back; the
+    caching allocator may hand that block to other tensors and then to the next forward's workspace again -- same address, same x,
+    same n, but the operand image of x in it has been overwritten.  The reuse of the image is only trusted on a workspace the
+    state kept, so the second forward must equal a fresh network's forward bit for bit."""
+    net, x, d = _net(golden)
+    fresh, _, _ = _net(golden)
+    want = host(fresh(x))
+    y0 = net(x)                                     # graph 1: forward only
+    first = host(y0)
+    del y0                                          # dropped: its workspace is freed, not given back
+    need = ops.siren_fit_workspace_bytes(net.desc(), x.shape[0])
+    junk = torch.full((need,), 0x5A, dtype=torch.uint8, device="cuda")       # very likely the block the workspace lived in
+    junk2 = torch.full((need,), 0xA5, dtype=torch.uint8, device="cuda")
+    del junk, junk2
+    second = host(net(x))
+    assert np.array_equal(first, want) and np.array_equal(second, want)
+    # and the normal cycle (forward, backward, forward) still reuses its workspace and stays bit-identical
+    net.zero_grad()
+    ((net(x) - 0.5) ** 2).mean().backward()
+    net.zero_grad()
+    assert np.array_equal(host(net(x)), want)
+
+
+def test_second_backward_on_one_forward_says_what_to_do(golden):
+    net, x, d = _net(golden)
+    y = net(x)
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="ONE backward per forward"):
+        y.sum().backward()
+    inr_mod.HP_AUTOGRAD = False                     # the layer-by-layer path supports it
+    try:
+        net.zero_grad()
+        y = net(x)
+        y.sum().backward(retain_graph=True)
+        g1 = [p.grad.clone() for p in net.parameters()]
+        y.sum().backward()
+        assert all(torch.allclose(p.grad, 2 * g) for p, g in zip(net.parameters(), g1))
+    finally:
+        inr_mod.HP_AUTOGRAD = True
+
+
+def test_switch_flipped_after_the_first_forward_falls_back(golden):
+    """Eligibility of the fused path also depends on the process-global diagnostic switches: asked per call, not cached."""
+    from mri_super_resolution_amd._lib import lib
+    net, x, d = _net(golden)
+    t = dev(d["lr_pixels"][0])
+    ((net(x) - t) ** 2).mean().backward()
+    g_hp = [host(p.grad).copy() for p in net.parameters()]
+    lib().inr_debug_set(3, 0)                       # exact-fp32 kernels only: the pre-split entry points refuse
+    try:
+        net.zero_grad()
+        ops.launch_counts_reset()
+        ((net(x) - t) ** 2).mean().backward()
+        assert ops.launch_counts()["f32_pipe16"] >= 11
+        for a, p in zip(g_hp, net.parameters()):
+            assert O.rel_l2(host(p.grad), a) < 1e-4
+    finally:
+        lib().inr_debug_set(3, 1)

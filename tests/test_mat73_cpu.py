@@ -102,3 +102,21 @@ def test_the_hybrid_entry_script_reads_v5_and_v73_master_files_alike(tmp_path):
     raw5, b5, te5 = S.load_hybrid(str(tmp_path / "v5.mat"))
     raw7, b7, te7 = S.load_hybrid(str(tmp_path / "v73.mat"))
     assert raw5.shape == (6, 6, 3, 4, 4) and np.array_equal(raw5, raw7) and np.array_equal(b5, b7) and np.array_equal(te5, te7)
+
+
+def test_stored_base_address_zero_behind_the_user_block(tmp_path):
+    """libhdf5 resolves every address against the place where it FOUND the superblock (the 512-byte user block) and
+    overrides the superblock's stored base-address field when the two differ -- a file whose stored field is 0 reads the same."""
+    rng = np.random.default_rng(4)
+    V = rng.random((6, 5, 4)).astype(np.float32)
+    got = {}
+    for stored in (512, 0):
+        w = Writer()
+        w.stored_base = stored
+        vars_ = {"V": w.dataset(V, "single", layout="chunked", chunk=(4, 3, 3)), "c": [np.arange(3.0), "txt"]}
+        path = str(tmp_path / f"b{stored}.mat")
+        write_mat73(path, vars_, w)
+        got[stored] = matio.loadmat(path)
+    for g in got.values():
+        assert np.array_equal(g["V"], V) and np.array_equal(np.asarray(g["c"].reshape(-1)[0]).reshape(-1), np.arange(3.0)) \
+            and g["c"].reshape(-1)[1] == "txt"
