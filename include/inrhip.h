@@ -455,7 +455,8 @@ int inr_debug_set_ptr(int key, void* ptr);   /* key 0: per-wave time-stamp buffe
 #define INR_LF_SMALL_STEP  9   /* small-network step kernel + reduce/Adam kernel */
 #define INR_LF_HP_NARROW   10  /* gemm_hp_nt_kernel: HL32 operands, 64 x 128 tiles (launches too small for the wide tiles) */
 #define INR_LF_HP_FUSED_FWD 11 /* siren_fwd_fused_kernel: every sine layer + the head of a forward in ONE launch, panel in LDS */
-#define INR_LF_COUNT       12
+#define INR_LF_HP_ROW      12  /* gemm_hp_row_kernel: HL32 operands, persistent, a block owns 128 rows x all 512 columns, epilogue in line */
+#define INR_LF_COUNT       13
 int inr_launch_count(int family, int64_t* count);
 int inr_launch_counts_reset(void);
 

@@ -16,7 +16,7 @@ c_stream = C.c_void_p
 
 
 INR_E_INVALID, INR_E_WORKSPACE, INR_E_ALIGN, INR_E_TIMEOUT = -1, -2, -3, -4     # include/inrhip.h
-INR_LF_COUNT = 12
+INR_LF_COUNT = 13
 
 
 class InrHipError(RuntimeError):

@@ -102,6 +102,7 @@ extern tune_int g_hp_head_rows;
 extern tune_int g_rams_epi_fuse;       // key 24 (rams.hip)
 extern tune_int g_reduce_onepass;      // key 25 (kernels.hip)
 extern tune_int g_rams_pregate_min_vox;   // key 26 (rams.hip)
+extern tune_int g_hp_row, g_hp_row_min_tiles;   // keys 27, 28 (gemm_f32.hip: the row-owning 128 x 512 kernel)
 extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
 int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const float* mul, int64_t n, int in_f, int out_f,
@@ -1275,6 +1276,10 @@ int inr_siren_loss_grad_ex(const inr_siren_desc_t* desc, const float* params, fl
     float* gy = (float*)((char*)y + c.out_b);
     float* scratch = (float*)((char*)gy + c.out_b);
     H3Ctx h3;
+    // A network the pre-split kernels do not serve keeps no operand image and no target statistics in its workspace: there is
+    // nothing a REUSE flag could refer to, so the flags are accepted and mean nothing (round 5: they were REFUSED, which made every
+    // multi-step ShardedSirenFitter.step on e.g. Siren(32, 64, 1, 1) fail at its second step -- found by tests/test_gpu_nccl.py).
+    if (!hp_eligible(desc, L)) flags = 0;
     const bool keep_x = (flags & INR_REUSE_INPUT_IMAGE) != 0;
     {
         std::lock_guard<std::mutex> lk(g_reuse_mu);
@@ -1727,6 +1732,7 @@ const DebugKey* debug_table(int* count) {
         {22, &g_hp_merge_blocks, 256, 28, 1024}, {23, &g_hp_head_rows, 0, 0, 4096},
         {24, &g_rams_epi_fuse, 2, 0, 2}, {25, &g_reduce_onepass, 1, 0, 1},
         {26, &g_rams_pregate_min_vox, 600000, 0, 1 << 30},
+        {27, &g_hp_row, 1, 0, 1},        {28, &g_hp_row_min_tiles, 1024, 1, 1 << 30},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -100,7 +100,8 @@ enum LaunchFamily {
     LF_SMALL_STEP = 9,  // siren_small step kernel pair
     LF_HP_NARROW = 10,  // gemm_hp_nt_kernel    64 x 128 tiles (launches that cannot fill the chip with wide tiles)
     LF_HP_FUSED_FWD = 11,   // siren_fwd_fused_kernel: all sine layers + head of an inference forward in one launch
-    LF_COUNT = 12
+    LF_HP_ROW = 12,     // gemm_hp_row_kernel   persistent, one block owns 128 rows x all 512 columns, epilogue in line (round 5)
+    LF_COUNT = 13
 };
 void count_launch(int family);
 #define INR_E_FALLBACK (-100)   // internal: the chosen kernel cannot run on this device, the caller takes its next-best path

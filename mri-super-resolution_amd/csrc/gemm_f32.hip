@@ -813,6 +813,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) INR_PACKED_F32 gemm_f32_pipe16_ke
 #include "gemm_h3.inc"
 #include "gemm_hp.inc"
 #include "gemm_hp_nt.inc"
+#include "gemm_hp_row.inc"
 #include "gemm_hp_fwd.inc"
 
 unsigned long long* g_stamps = nullptr;  // diagnostic builds only
@@ -824,7 +825,7 @@ int gemm_build_flags() {
 #endif
     if (H3_ABLATE != 0 || HP_ABLATE != 0) f |= 2;
     if (H3_EXTRA_LDS != 0) f |= 4;
-    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1 || HP_HEAD_PREFETCH != 1 || HP_COLSUM_TRANSPOSED != 1) f |= 8;     // cache-policy experiments (gemm_hp.inc)
+    if (HP_A_AUX != 2 || HP_MUL_AUX != 0 || HP_RC_A_AUX != 0 || HP_RC_B_AUX != 0 || HP_HEAD_NT != 0 || HP_UNSCALE_LDEXP != 1 || HP_HEAD_PREFETCH != 1 || HP_COLSUM_TRANSPOSED != 1 || HP_DIAG_NO_OMEGA_STASH != 0) f |= 8;     // cache-policy experiments (gemm_hp.inc)
     return f;
 }
 static unsigned long long* hp_stamp_target(int kernel_class) {
@@ -1185,6 +1186,15 @@ tune_int g_hp_zhead{1};
 tune_int g_hp_fused_fwd{0};   // inr_debug_set(19, 1): inference forwards of eligible networks run all layers in one launch (gemm_hp_fwd.inc:
                               // measured SLOWER than the layer-wise launches at hidden = 512 -- 117 against 144 M voxels/s -- so off by default)
 tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
+// The row-owning kernel (gemm_hp_row.inc) takes the K-contiguous launches of 512 output columns whose 128-row panels give every CU
+// at least g_hp_row_min_tiles / 256 tiles (its tiles are twice the size of the 128 x 256 ones: below that the last, partly filled round
+// of the persistent grid weighs more than the cheaper K-loop saves).  inr_debug_set(27, 0) switches it off (A/B; the results are
+// bit-identical either way), key 28 moves the threshold.
+tune_int g_hp_row{1};
+tune_int g_hp_row_min_tiles{1024};
+static bool hp_row_ok(int64_t rows, int n_cols, int k) {
+    return g_hp_row && g_hp_persistent == 2 && n_cols == HR_BN && k % 64 == 0 && k >= 128 && (rows + HP_BM - 1) / HP_BM >= g_hp_row_min_tiles;
+}
 bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
 
 // Which rows of a K-contiguous GEMM go to the wide persistent kernels and which to the 64 x 128 tiles of gemm_hp_nt_kernel:
@@ -1248,7 +1258,14 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
         const long long tiles = (long long)p.tiles_m * p.tiles_n;
         const dim3 grid((unsigned)tiles), block(HP_NTH);
         const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-        if (z_only) {   // z + b as fp32 into `dact`, nothing else
+        if (hp_row_ok(plan.wide_rows, out_f, in_f)) {   // one block per 128 rows x all 512 columns (gemm_hp_row.inc)
+            p.tiles_n = 1;
+            const dim3 rgrid((unsigned)(p.tiles_m < hp_num_cus() ? p.tiles_m : hp_num_cus()));
+            if (z_only) hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_Z>), rgrid, block, 0, stream, p);
+            else if (dact) hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_SINE_STASH>), rgrid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_SINE>), rgrid, block, 0, stream, p);
+            count_launch(LF_HP_ROW);
+        } else if (z_only) {   // z + b as fp32 into `dact`, nothing else
             if (in_f == 512) hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 16>), pgrid, block, 0, stream, p);
             else hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_Z, 8>), pgrid, block, 0, stream, p);
             count_launch(LF_HP_PKD);
@@ -1312,7 +1329,12 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
         const long long tiles = (long long)p.tiles_m * p.tiles_n;
         const dim3 grid((unsigned)tiles), block(HP_NTH);
         const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-        if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
+        if (hp_row_ok(plan.wide_rows, in_f, out_f)) {
+            p.tiles_n = 1;
+            const dim3 rgrid((unsigned)(p.tiles_m < hp_num_cus() ? p.tiles_m : hp_num_cus()));
+            hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_MUL>), rgrid, block, 0, stream, p);
+            count_launch(LF_HP_ROW);
+        } else if (g_hp_persistent == 2 && out_f == 512) {   // (K = 256 would spill: the in-line epilogue serves it)
             hipLaunchKernelGGL((gemm_hp_pkd_kernel<HPE_MUL, 16>), pgrid, block, 0, stream, p);
             count_launch(LF_HP_PKD);
         } else if (g_hp_persistent && out_f >= 3 * HP_BK) {

@@ -504,7 +504,7 @@ def siren_backward_train(desc: SirenDesc, params, grads, gy, workspace):
 
 # ---- diagnostics ------------------------------------------------------------------------------------------
 LAUNCH_FAMILIES = ("hp_pkd", "hp_pkc", "hp_tile", "hp_rc", "h3", "f32_pipe16", "f32_pipe", "f32_generic", "small_multi",
-                   "small_step", "hp_narrow", "hp_fused_fwd")   # INR_LF_* of include/inrhip.h, in order
+                   "small_step", "hp_narrow", "hp_fused_fwd", "hp_row")   # INR_LF_* of include/inrhip.h, in order
 
 
 def launch_counts() -> dict:

@@ -98,8 +98,10 @@ def test_run_volumes_concurrent_fits_keep_their_bits():
             raise RuntimeError("boom")
         return drivers.fit_volume(volume, steps=steps, return_recon=return_recon, **kw2)
 
-    recs = drivers.run_volumes(vols, concurrent=2, fit_fn=flaky, requeue=False, **kw)
+    recs = drivers.run_volumes(vols, concurrent=2, fit_fn=flaky, requeue=False, errors="record", **kw)
     assert [r["status"] for r in recs] == [drivers.FIT_ERROR if v.shape[0] == 28 else drivers.FIT_OK for v in vols]
+    with pytest.raises(RuntimeError, match="boom"):           # the default: one process, nobody to take the fit over -- it raises
+        drivers.run_volumes(vols, concurrent=2, fit_fn=flaky, requeue=False, **kw)
 
 
 def test_fit_volume_cfg2_short(golden):

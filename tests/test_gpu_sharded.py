@@ -217,3 +217,21 @@ def test_fit_hybrid_echo_times_spread_over_ranks():
     # half-precision target storage (BASELINE config 5): the same flow from a float16 copy of the normalised volume
     h0, _ = run_ranks(_hybrid_worker, 2, (True,), timeout=300)
     assert np.abs(h0["signals"] - ws).max() / np.abs(ws).max() < 5e-3
+
+
+def test_multi_step_call_on_a_network_the_pre_split_kernels_do_not_serve():
+    """Round 5 (found by tests/test_gpu_nccl.py): from its second step on `ShardedSirenFitter.step` passes INR_REUSE_* -- for a
+    network outside the pre-split kernels (hidden 64: no operand image exists) the flags must mean nothing, not fail the call."""
+    from oracle import torch_port as P
+    n = 360
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(n, 32, generator=g) * 2 - 1
+    t = torch.rand(n, 1, generator=g)
+    torch.manual_seed(0)
+    net = inr.Siren(32, 64, 1, 1).cuda()
+    assert not ops.siren_hp_eligible(net.desc())
+    fitter = inr.ShardedSirenFitter(net, global_rows=n, lr=1e-4)
+    losses = fitter.step(x.cuda(), t.cuda(), 5).cpu().numpy()
+    torch.manual_seed(0)
+    ref_losses, _ = P.port_fit(P.PortSiren(32, 64, 1, 1), x, t, 5, lr=1e-4)
+    assert np.allclose(losses, ref_losses, rtol=1e-4)

@@ -46,6 +46,8 @@ struct Args {
     int tiles;           // tiles per block
     int dma;
     long long a_tile_bytes;
+    int share;           // V0..V3: 1 = two consecutive 128 x 256 tiles read the SAME A panel (the product: the two column tiles of a row
+                         // panel; the second read comes from L2), 0 = every tile streams its own panel from HBM
 };
 
 // WAVES: 8 or 4.  M32: 32x32x16 MFMA.
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) kloop(const Ar
     }
     const int total = p.tiles * p.ktiles;     // (even)
     auto a_srd = [&](int t) {
-        return srd(p.A + ((long long)blockIdx.x * p.tiles + t / p.ktiles) * p.a_tile_bytes, (unsigned)p.a_tile_bytes);
+        return srd(p.A + ((long long)blockIdx.x * p.tiles + ((t / p.ktiles) >> p.share)) * p.a_tile_bytes, (unsigned)p.a_tile_bytes);
     };
     // fragment register sets (two: K-tile t computes on one while t+1's fragments land in the other, as in the product kernel)
     half8 ah[2][4], al[2][4], bh[2][NB], bl[2][NB];      // 16x16x32: [set][fragment]; 32x32x16: [set][2 * block + k-step]
@@ -231,6 +233,108 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) kloop(const Ar
     p.out[(long long)blockIdx.x * WAVES * 64 + tid] = s;
 }
 
+
+// V4: the ROW-OWNING shape of verdict r04 item 5 (b) -- one block owns 128 rows x all 512 columns (the head step could then run
+// in the last sine layer's epilogue: y_n needs the whole row): 8 waves (2 x 4) of 64 x 128, 128 accumulator registers per lane and NO
+// second register set (the epilogue would run in line), a stage = A 16 KB + B 64 KB = 80 KB, so the 160 KB LDS hold a TWO-stage ring:
+// K-tile t+1 lands while t computes, its fragments can only be read behind the barrier that ends iteration t (single fragment set).
+constexpr int R_A_IMG = 16384, R_B_IMG = 65536, R_STAGE = R_A_IMG + R_B_IMG;
+__global__ void __launch_bounds__(512, 2) kloop_rowown(const Args p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * R_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    for (int i = tid; i < 2 * R_STAGE / 16; i += 512)
+        reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(p.B)[i % (256 * 128 / 16 * 4)];
+    __syncthreads();
+    const int drow = lane >> 3;
+    const __amdgpu_buffer_rsrc_t srdB = srd(p.B, 512u * (unsigned)p.ktiles * 128u);
+    // a K-tile = 80 transfers of 1 KB (8 rows x 128 B): wave w issues q = w, w + 8, ... (ten each): q < 16 A rows, else B rows
+    auto dma_tile = [&](int stage, const __amdgpu_buffer_rsrc_t& sa, int kt) {
+        char* S = smem + stage * R_STAGE;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int q = wave + 8 * i;
+            const bool isA = q < 16;
+            const int row0 = 8 * (isA ? q : q - 16);
+            const int voff = (row0 + drow) * p.ktiles * 128 + (((lane & 7) ^ hp_f(row0 + drow)) * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? sa : srdB, (__attribute__((address_space(3))) void*)(S + q * 1024), 16, voff,
+                                                     kt * 128, 0, 0);
+        }
+    };
+    const int g = lane >> 4, l16 = lane & 15;
+    const int fx = (g ^ hp_f(l16)) << 4;
+    const int fa = (64 * wm + l16) * 128 + fx;
+    const int fb = R_A_IMG + (128 * wn + l16) * 128 + fx;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    const int total = p.tiles * p.ktiles;
+    auto a_srd = [&](int t) {
+        return srd(p.A + ((long long)blockIdx.x * p.tiles + t / p.ktiles) * p.a_tile_bytes, (unsigned)p.a_tile_bytes);
+    };
+    if (p.dma) {
+        dma_tile(0, a_srd(0), 0);
+        dma_tile(1, a_srd(1), 1 % p.ktiles);
+        __builtin_amdgcn_s_waitcnt(0x0F70 | 10);      // vmcnt(10): K-tile 0 has landed, K-tile 1 in flight
+    }
+    __builtin_amdgcn_s_barrier();
+    half8 ah[4], al[4], bh[8], bl[8];
+    for (int t = 0; t < total; ++t) {
+        const char* S = smem + (t & 1) * R_STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ah[i] = *reinterpret_cast<const half8*>(S + fa + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const half8*>(S + (fb ^ 64) + j * 2048);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bh[j] = *reinterpret_cast<const half8*>(S + fb + j * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) al[i] = *reinterpret_cast<const half8*>(S + (fa ^ 64) + i * 2048);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        // K-tile t+1 has landed (this wave's transfers), everybody is done with stage t & 1: refill it with K-tile t+2
+        if (p.dma) __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        if (p.dma && t + 2 < total) dma_tile(t & 1, a_srd(t + 2), (t + 2) % p.ktiles);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (tid == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        p.clk[blockIdx.x * 4 + 0] = t0;
+        p.clk[blockIdx.x * 4 + 1] = r0;
+        p.clk[blockIdx.x * 4 + 2] = t1;
+        p.clk[blockIdx.x * 4 + 3] = r1;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    p.out[(long long)blockIdx.x * 512 + tid] = sum;
+}
+static void launch_rowown(const Args& a, int blocks) {
+    Args b = a;
+    b.share = 0;
+    b.tiles = a.tiles / 2;        // 128 x 512 tiles: half as many per block for the same FLOPs (and half the A bytes)
+    hipLaunchKernelGGL(kloop_rowown, dim3(blocks), dim3(512), 0, 0, b);
+}
+
 struct Var {
     const char* name;
     void (*launch)(const Args&, int blocks);
@@ -244,11 +348,13 @@ static void launch(const Args& a, int blocks) {
 
 int main(int argc, char** argv) {
     double secs = 12;
-    int rounds = 2, dma = 1;
+    int rounds = 2, dma = 1, only = -1, share = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--secs")) secs = atof(argv[i + 1]);
         if (!strcmp(argv[i], "--rounds")) rounds = atoi(argv[i + 1]);
         if (!strcmp(argv[i], "--dma")) dma = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--share")) share = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--only")) only = atoi(argv[i + 1]);      // V0 and this variant only
     }
     const int blocks = 256, ktiles = 16, tiles = 32;     // a launch = 32 tiles x 16 K-tiles per block (the 128^3 forward: 32 tiles per CU)
     const long long a_tile = 128ll * ktiles * 128;       // bytes of one 128-row A panel
@@ -257,12 +363,12 @@ int main(int argc, char** argv) {
     float* out;
     unsigned long long* clk;
     hipMalloc(&A, a_bytes);
-    hipMalloc(&B, 256 * ktiles * 128 + NSTAGE * STAGE);
+    hipMalloc(&B, 512 * ktiles * 128 + 2 * R_STAGE);
     hipMalloc(&out, (size_t)blocks * 512 * 4);
     hipMalloc(&clk, blocks * 4 * 8);
     {   // random HL32 lines: hi ~ uniform in [-2^14, 2^14), lo up to half an ulp of hi
         std::mt19937 rng(1);
-        std::vector<_Float16> h((256 * ktiles * 128 + NSTAGE * STAGE) / 2);
+        std::vector<_Float16> h((512 * ktiles * 128 + 2 * R_STAGE) / 2);
         auto fill = [&](std::vector<_Float16>& v) {
             for (size_t line = 0; line + 64 <= v.size(); line += 64)
                 for (int e = 0; e < 32; ++e) {
@@ -278,9 +384,15 @@ int main(int argc, char** argv) {
         for (size_t off = 0; off < a_bytes; off += (64 << 20))
             hipMemcpy(A + off, ha.data(), std::min<size_t>(64 << 20, a_bytes - off), hipMemcpyHostToDevice);
     }
-    Args a{A, B, out, clk, ktiles, tiles, dma, a_tile};
-    Var vars[4] = {{"V0 8w 64x64  16x16x32", launch<8, false>, 8}, {"V1 8w 64x64  32x32x16", launch<8, true>, 8},
-                   {"V2 4w 64x128 16x16x32", launch<4, false>, 4}, {"V3 4w 64x128 32x32x16", launch<4, true>, 4}};
+    Args a{A, B, out, clk, ktiles, tiles, dma, a_tile, share};
+    std::vector<Var> vars = {{"V0 8w 64x64  16x16x32", launch<8, false>, 8}, {"V1 8w 64x64  32x32x16", launch<8, true>, 8},
+                             {"V2 4w 64x128 16x16x32", launch<4, false>, 4}, {"V3 4w 64x128 32x32x16", launch<4, true>, 4},
+                             {"V4 8w 64x128 row-owning 128x512, 2 stages", launch_rowown, 8}};
+    if (only >= 0) {
+        std::vector<Var> pick = {vars[0], vars[only]};
+        if (only == 0) pick.pop_back();
+        vars = pick;
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
