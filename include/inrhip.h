@@ -432,7 +432,9 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * 0 = the separate passes they replaced, 2 (default) = also the inference gate of an attention block computed from its first
  * convolution's output so that the second applies it and adds the residual itself (equal up to the rounding of a mean); key 25 = tall slab reductions (more than 128 partial sums per output) in one
  * launch (1, default) or two (0; the same additions in the same order); key 26 = fewest voxels (batch x image) for which RAMS
- * inference takes the gate-ahead form of key 24 = 2 (600,000 default: four 128 x 128 x 9 stacks);
+ * inference takes the gate-ahead form of key 24 = 2 (600,000 default: four 128 x 128 x 9 stacks); key 27 = 1 sends the K-contiguous
+ * GEMMs of 512 output columns to the row-owning kernel (a block owns 128 rows x all 512 columns, epilogue in line; 0 = default: measured
+ * slower, bit-identical) when they have at least key-28 (default 1024) row panels;
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

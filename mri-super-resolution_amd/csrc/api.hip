@@ -1732,7 +1732,7 @@ const DebugKey* debug_table(int* count) {
         {22, &g_hp_merge_blocks, 256, 28, 1024}, {23, &g_hp_head_rows, 0, 0, 4096},
         {24, &g_rams_epi_fuse, 2, 0, 2}, {25, &g_reduce_onepass, 1, 0, 1},
         {26, &g_rams_pregate_min_vox, 600000, 0, 1 << 30},
-        {27, &g_hp_row, 1, 0, 1},        {28, &g_hp_row_min_tiles, 1024, 1, 1 << 30},
+        {27, &g_hp_row, 0, 0, 1},        {28, &g_hp_row_min_tiles, 1024, 1, 1 << 30},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -1186,11 +1186,13 @@ tune_int g_hp_zhead{1};
 tune_int g_hp_fused_fwd{0};   // inr_debug_set(19, 1): inference forwards of eligible networks run all layers in one launch (gemm_hp_fwd.inc:
                               // measured SLOWER than the layer-wise launches at hidden = 512 -- 117 against 144 M voxels/s -- so off by default)
 tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
-// The row-owning kernel (gemm_hp_row.inc) takes the K-contiguous launches of 512 output columns whose 128-row panels give every CU
-// at least g_hp_row_min_tiles / 256 tiles (its tiles are twice the size of the 128 x 256 ones: below that the last, partly filled round
-// of the persistent grid weighs more than the cheaper K-loop saves).  inr_debug_set(27, 0) switches it off (A/B; the results are
-// bit-identical either way), key 28 moves the threshold.
-tune_int g_hp_row{1};
+// The row-owning kernel (gemm_hp_row.inc): K-contiguous launches of 512 output columns whose 128-row panels number at least
+// g_hp_row_min_tiles.  OFF by default (inr_debug_set(27, 1) selects it, key 28 moves the threshold; bit-identical results either way):
+// its K-loop is 10 % cheaper than the 128 x 256 shape's (tools/kloop_probe.hip V4 / V0: 0.631 against 0.702 ms at the package cap) but
+// it has no registers for a second accumulator set, and the epilogue it therefore runs in line costs 0.19 ms per launch with the
+// matrix pipe idle: forward 0.815 against 0.753 ms, input gradient 0.931 against 0.842, step 8.85 against 8.46 ms at 128^3
+// (profiles/r05_headline_ab.txt).
+tune_int g_hp_row{0};
 tune_int g_hp_row_min_tiles{1024};
 static bool hp_row_ok(int64_t rows, int n_cols, int k) {
     return g_hp_row && g_hp_persistent == 2 && n_cols == HR_BN && k % 64 == 0 && k >= 128 && (rows + HP_BM - 1) / HP_BM >= g_hp_row_min_tiles;

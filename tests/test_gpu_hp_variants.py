@@ -86,12 +86,16 @@ def row_plan(n, width, persistent=2, narrow=1):
     return (0, n) if 4 * tiles_m * tiles_n <= 3 * CUS else (n, 0)
 
 
-def kc_families(K, deferred_ok, n, width, persistent=2, narrow=1):
+def kc_families(K, deferred_ok, n, width, persistent=2, narrow=1, row=0, row_min_tiles=1024):
     """families one K-contiguous GEMM (forward or input-grad) of `n` rows and `width` output columns launches"""
     wide, nar = row_plan(n, width, persistent, narrow)
     out = []
     if wide:
-        out.append("hp_pkd" if persistent == 2 and deferred_ok else "hp_pkc" if persistent and K >= 96 else "hp_tile")
+        # hp_row_ok of csrc/gemm_f32.hip: the row-owning kernel takes 512-column launches with enough 128-row panels
+        if row and persistent == 2 and width == 512 and K % 64 == 0 and K >= 128 and (wide + 127) // 128 >= row_min_tiles:
+            out.append("hp_row")
+        else:
+            out.append("hp_pkd" if persistent == 2 and deferred_ok else "hp_pkc" if persistent and K >= 96 else "hp_tile")
     if nar:
         out.append("hp_narrow")
     return out
@@ -441,3 +445,38 @@ def test_reconstruct_builds_its_input_as_hl32_directly(shape, m, hidden):
     ref = P.PortSiren(2 * m, hidden, 2, 1)
     ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=False)
     assert O.rel_l2(got, P.port_reconstruct(ref, shape, B.cpu())) < T1
+
+
+@pytest.mark.parametrize("fin,n", [(256, 128 * 40 + 77), (512, 128 * 33), (128, 128 * 9 + 1), (64, 2000)])
+def test_row_owning_kernel_is_bit_identical_to_the_deferred_epilogue_kernel(fin, n):
+    """gemm_hp_row_kernel (round 5: one block owns 128 rows x all 512 columns, two 80 KB LDS stages, epilogue in line) against
+    gemm_hp_pkd / pkc_kernel on the same launches: every accumulator sees the same sequence of MFMAs and the epilogue is the same
+    chunk arithmetic, so a 6-step fit (forward with stash, last layer z-only, input gradients with column sums and maxima), the
+    losses and an inference forward agree BIT FOR BIT -- ragged last panel, K = 64 ... 512, one tile per CU or several."""
+    from mri_super_resolution_amd._lib import lib
+    g = torch.Generator().manual_seed(n)
+    x = (torch.rand(n, fin, generator=g) * 2 - 1).cuda()
+    t = torch.rand(n, generator=g).cuda()
+    w = (torch.rand(n, generator=g) + 0.5).cuda()
+    out = {}
+    for row in (0, 1):
+        lib().inr_debug_set(18, 0)            # no narrow tiles: the wide dispatch decides
+        lib().inr_debug_set(27, row)
+        lib().inr_debug_set(28, 1)            # any panel count
+        torch.manual_seed(0)
+        net = inr.Siren(fin, 512, 2, 1).cuda()
+        fitter = inr.SirenFitter(net, lr=1e-4)
+        ops.launch_counts_reset()
+        losses = fitter.step(x, t, 6, w)
+        torch.cuda.synchronize()
+        c = ops.launch_counts()
+        desc, flat = inr.flat_parameters(net)
+        y = ops.siren_forward(desc, flat, x)
+        out[row] = (losses.cpu().numpy(), fitter.flat.cpu().numpy(), y.cpu().numpy(), c)
+        lib().inr_debug_reset()
+    (l0, f0, y0, c0), (l1, f1, y1, c1) = out[0], out[1]
+    assert c0["hp_row"] == 0 and c0["hp_pkd"] + c0["hp_pkc"] > 0
+    want_row = 6 * (3 + 2) if fin % 64 == 0 and fin >= 128 else 6 * (2 + 2)       # per step: forward layers + input-grad layers served
+    assert c1["hp_row"] == want_row, c1
+    assert np.array_equal(l0, l1) and np.array_equal(f0, f1) and np.array_equal(y0, y1)
+    assert np.isfinite(l1).all() and l1[-1] < l1[0]
