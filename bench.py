@@ -120,6 +120,25 @@ def sample_power(out):
         out["error"] = str(e)[:100]
 
 
+NOMINAL_SCLK_MHZ = 2400.0         # the clock the dense MFMA peaks of MI355X_MICROARCH.md are quoted at
+
+
+def add_clock_adjusted(roofline, sclk_mhz, source, watts=None):
+    """The MFMA fractions of the bench line beside the peak the HELD shader clock allows (peak x sclk / 2.4 GHz): the fused steps sit
+    at the 1,400 W package cap, where the chip holds ~1.6 GHz, so "0.37 of nominal" is ~0.55 of what the cap leaves.  HBM bandwidth does
+    not scale with the shader clock: the HBM fraction stays as it is."""
+    scale = sclk_mhz / NOMINAL_SCLK_MHZ
+    peak = PEAK_F16_MFMA_TFLOPS * scale
+    k = roofline.get("mfma_of_this_kernel", {})
+    m = roofline.get("mfma", {})
+    roofline["clock_adjusted"] = {
+        "sclk_mhz": sclk_mhz, "nominal_sclk_mhz": NOMINAL_SCLK_MHZ, "package_watts": watts, "source": source,
+        "fp16_mfma_peak_at_held_clock_tflops": peak,
+        "dominant_kernel_frac_executed": (k.get("executed_tflops") / peak) if k.get("executed_tflops") else None,
+        "whole_step_frac_executed": (m.get("executed_tflops") / peak) if m.get("executed_tflops") else None,
+        "hbm": "clock-independent: roofline.frac stands"}
+
+
 def cfg1_quality(inr, steps=2500, max_seeds=60):
     """Config 1 on the committed real slice: fit the 64x64 LR of pat07 slice 11, PSNR of the x2 recon vs HR, for every seed the
     REAL reference was run at (tests/golden/cfg1_ref_psnr.npz, oracle/gen_golden_t4.py; seed s drives the Fourier matrix and the
@@ -166,7 +185,8 @@ def cfg1_quality(inr, steps=2500, max_seeds=60):
             "reference_cpu_psnr_db_trimmed_mean": float(np.sort(ref_db)[1:-1].mean()),
             "psnr_db_per_seed": [round(v, 3) for v in psnrs], "reference_cpu_psnr_db_per_seed": [round(float(v), 3) for v in ref_db],
             "note": "delta = mean(ours) - mean(reference), se = two-sample standard error; a fit caught on an Adam spike at step "
-                    "2,500 is several dB down for ~50 steps (profiles/r03_t4_study.json holds the per-step traces)",
+                    "2,500 is several dB down for ~50 steps (profiles/r05_t4_paths.json: sixty seeds on both arithmetic paths, per-seed traces and spike "
+                    "statistics -- the paths are statistically indistinguishable, each has one such seed)",
             "final_loss_seed0": finals[0], "fit_recon_eval_seconds_seed0": dts[0],
             "train_voxels_per_s": res["n_coords"] * steps / res["t_fit"]}
 
@@ -561,7 +581,7 @@ def main():
     # WRITE_SIZE, separate --pmc passes, written by tools/save_profiles.py together with the hash of the kernel sources it
     # was measured on).  A summary taken from other sources is stale: traffic is then null.
     traffic, traffic_by_class, traffic_src, src_hash = None, None, None, source_hash()
-    pmc_path = os.path.join(ROOT, "profiles", "r03_fp32mfma_pmc_hbm.json" if args.fp32_mfma else "r04_pmc_hbm.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_fp32mfma_pmc_hbm.json" if args.fp32_mfma else "r05_pmc_hbm.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as fh:
             pm = json.load(fh)
@@ -624,7 +644,8 @@ def main():
                     "vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                     "power_note": "peaks are the nominal 2.4 GHz figures; during these steps the package sits at its 1,400 W cap and "
                                   "the shader clock at 1.63 GHz (84 rocm-smi samples over 36 s: profiles/r04_ablate_power.txt; the "
-                                  "K-loop alone holds 2.35 GHz at 1,171 W, the epilogue alone 2.30 GHz at 1,270 W)"}
+                                  "dominant kernel's K-loop alone, on random operands, holds the package at the cap as well: "
+                                  "profiles/r05_kloop_rowown_probe_shared_a.txt); clock-adjusted fractions: roofline.clock_adjusted"}
     ops.prof_reset()
 
     out = {"metric": "voxels/sec per INR fit (128^3, x4 upscale): train coordinate-steps/s",
@@ -699,6 +720,10 @@ def main():
                                "e2e_voxels_per_s": n_test / (t_fit + t_inf), "final_loss": float(full_losses[-1]),
                                "power_during_fit": telemetry or None}
             del rec, net_full
+            held = (telemetry or {}).get("sclk_mhz")
+            if held and "mfma" in roofline and not args.fp32_mfma:
+                add_clock_adjusted(roofline, float(held), "rocm-smi, 6 s into this run's 2,500-step fit (the same kernels, the package at its cap)",
+                                   telemetry.get("package_watts"))
         out["compat_loop"] = compat_loop_leg(x, target, steps=max(5, min(args.steps, 20)))
         out["compat_loop"]["vs_fused_step"] = out["compat_loop"]["ms_per_step"] / out["ms_per_step"]
         out["quality"] = cfg1_quality(inr)
@@ -710,6 +735,9 @@ def main():
             out["cfg4_eleven_patients"] = cfg4_leg()
         out["cfg5_te_fits"] = cfg5_leg()
         out["hybrid_fit"] = hybrid_fit_leg()
+    if world == 1 and not args.fp32_mfma and "clock_adjusted" not in roofline:
+        add_clock_adjusted(roofline, 1630.0, "profiles/r04_ablate_power.txt (84 rocm-smi samples over 36 s of these steps; not sampled in this run)",
+                           1400.0)
     if not args.no_cpu_baseline and world == 1:
         ncpu = os.cpu_count() or 1
         # (profiles/r04_cpu_baseline.json: 5 + 20 steps with a sweep over 32 .. 256 threads on the 2 x 64-core host -- 32 threads win)

@@ -1194,8 +1194,11 @@ tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128
 // (profiles/r05_headline_ab.txt).
 tune_int g_hp_row{0};
 tune_int g_hp_row_min_tiles{1024};
-static bool hp_row_ok(int64_t rows, int n_cols, int k) {
-    return g_hp_row && g_hp_persistent == 2 && n_cols == HR_BN && k % 64 == 0 && k >= 128 && (rows + HP_BM - 1) / HP_BM >= g_hp_row_min_tiles;
+// (only the launches the deferred-epilogue kernel serves -- forward K = 256 / 512, input gradient K = 512: that kernel's MFMA block order
+//  is the one this kernel reproduces bit for bit; the in-line kernel that takes the other K runs its blocks in another order)
+static bool hp_row_ok(int64_t rows, int n_cols, int k, bool forward) {
+    return g_hp_row && g_hp_persistent == 2 && n_cols == HR_BN && (k == 512 || (forward && k == 256)) &&
+           (rows + HP_BM - 1) / HP_BM >= g_hp_row_min_tiles;
 }
 bool hp_z_stash_ok(int in_f) { return g_hp_zhead && g_hp_persistent == 2 && (in_f == 512 || in_f == 256); }
 
@@ -1260,7 +1263,7 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
         const long long tiles = (long long)p.tiles_m * p.tiles_n;
         const dim3 grid((unsigned)tiles), block(HP_NTH);
         const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-        if (hp_row_ok(plan.wide_rows, out_f, in_f)) {   // one block per 128 rows x all 512 columns (gemm_hp_row.inc)
+        if (hp_row_ok(plan.wide_rows, out_f, in_f, true)) {   // one block per 128 rows x all 512 columns (gemm_hp_row.inc)
             p.tiles_n = 1;
             const dim3 rgrid((unsigned)(p.tiles_m < hp_num_cus() ? p.tiles_m : hp_num_cus()));
             if (z_only) hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_Z>), rgrid, block, 0, stream, p);
@@ -1331,7 +1334,7 @@ int hp_input_grad(char* dzprev_hl, const char* dz_hl, const char* WT_hl, const f
         const long long tiles = (long long)p.tiles_m * p.tiles_n;
         const dim3 grid((unsigned)tiles), block(HP_NTH);
         const dim3 pgrid((unsigned)(tiles < hp_num_cus() ? tiles : hp_num_cus()));
-        if (hp_row_ok(plan.wide_rows, in_f, out_f)) {
+        if (hp_row_ok(plan.wide_rows, in_f, out_f, false)) {
             p.tiles_n = 1;
             const dim3 rgrid((unsigned)(p.tiles_m < hp_num_cus() ? p.tiles_m : hp_num_cus()));
             hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_MUL>), rgrid, block, 0, stream, p);
