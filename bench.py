@@ -348,7 +348,7 @@ def compat_loop_leg(x, target, steps=20, warmup=3):
                 inr_optim.step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / k
-            final = float(loss)
+            final = float(loss.detach())
             del INR, inr_optim, model_output, loss
             torch.cuda.empty_cache()
             return dt, final

@@ -102,6 +102,7 @@ extern tune_int g_hp_head_rows;
 extern tune_int g_rams_epi_fuse;       // key 24 (rams.hip)
 extern tune_int g_reduce_onepass;      // key 25 (kernels.hip)
 extern tune_int g_rams_pregate_min_vox;   // key 26 (rams.hip)
+extern tune_int g_hp_narrow_max_tiles;   // key 29 (gemm_f32.hip)
 extern tune_int g_hp_row, g_hp_row_min_tiles;   // keys 27, 28 (gemm_f32.hip: the row-owning 128 x 512 kernel)
 extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
@@ -1733,6 +1734,7 @@ const DebugKey* debug_table(int* count) {
         {24, &g_rams_epi_fuse, 2, 0, 2}, {25, &g_reduce_onepass, 1, 0, 1},
         {26, &g_rams_pregate_min_vox, 600000, 0, 1 << 30},
         {27, &g_hp_row, 0, 0, 1},        {28, &g_hp_row_min_tiles, 1024, 1, 1 << 30},
+        {29, &g_hp_narrow_max_tiles, 192, 0, 1 << 30},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

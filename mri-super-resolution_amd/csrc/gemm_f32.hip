@@ -1185,6 +1185,7 @@ static int hp_check_grid(const HpParams& p) {
 tune_int g_hp_zhead{1};
 tune_int g_hp_fused_fwd{0};   // inr_debug_set(19, 1): inference forwards of eligible networks run all layers in one launch (gemm_hp_fwd.inc:
                               // measured SLOWER than the layer-wise launches at hidden = 512 -- 117 against 144 M voxels/s -- so off by default)
+tune_int g_hp_narrow_max_tiles{192};   // inr_debug_set(29, v): most wide tiles (per 256 CUs) of a launch that still goes to the narrow kernel
 tune_int g_hp_narrow{1};    // inr_debug_set(18, v): 1 = launches with fewer 128-row tiles than two per CU take 64-row tiles (default), 0 = never
 // The row-owning kernel (gemm_hp_row.inc): K-contiguous launches of 512 output columns whose 128-row panels number at least
 // g_hp_row_min_tiles.  OFF by default (inr_debug_set(27, 1) selects it, key 28 moves the threshold; bit-identical results either way):
@@ -1212,7 +1213,7 @@ static HpRowPlan hp_row_plan(int64_t n, int width) {
     if (!g_hp_narrow || !g_hp_persistent) return {n, 0};
     const long long G = hp_num_cus();
     const long long tiles_n = (width + HP_BN - 1) / HP_BN, tiles_m = (n + HP_BM - 1) / HP_BM, tiles = tiles_m * tiles_n;
-    if (4 * tiles <= 3 * G) return {0, n};
+    if (256 * tiles <= (long long)g_hp_narrow_max_tiles * G) return {0, n};   // (default 192 per 256 CUs: three quarters of the chip)
     // (Handing the remainder rows of a LARGE launch to the narrow tiles was measured and dropped: these kernels move their
     //  bytes at ~3.6 TB/s whatever the tile count, so the round the remainder adds to a few CUs costs ~9 us at 69,632 rows,
     //  less than a second launch: 1.39 against 1.34 ms per step.)
