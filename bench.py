@@ -236,7 +236,7 @@ def cfg4_leg(steps=2500):
             "modelled_8_gpu_plan": {"gangs": [[j, r] for j, r in plan8["gangs"]], "whole": plan8["whole"],
                                     "makespan_s": plan8["makespan"], "per_rank_s": plan8["loads"], "one_rank_s_model": plan8["one_rank"]},
             "modelled_note": "makespan from dist.StepTimeModel: per-fit and per-shard step times MEASURED on one GPU "
-                             "(profiles/r04_step_time_table.json), the per-step all-reduce of a row-sharded fit MODELLED (RCCL has "
+                             "(profiles/r05_step_time_table.json), the per-step all-reduce of a row-sharded fit MODELLED (RCCL has "
                              "not run: no multi-GPU node); divided into THIS run's measured one-GPU seconds"}
 
 

@@ -68,8 +68,8 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
     return groups
 
 
-# Fit-step time of Siren(256,512,3,1) on one MI355X, milliseconds per step by row count: MEASURED (round 4:
-# tools/step_time_table.py -> profiles/r04_step_time_table.json; tests/test_dist_cpu.py holds this table to that file).  `fused` = inr_siren_fit (a whole volume on one rank),
+# Fit-step time of Siren(256,512,3,1) on one MI355X, milliseconds per step by row count: MEASURED (round 5:
+# tools/step_time_table.py -> profiles/r05_step_time_table.json; tests/test_dist_cpu.py holds this table to that file).  `fused` = inr_siren_fit (a whole volume on one rank),
 # `sharded` = inr_siren_loss_grad + inr_adam_step per step (what a gang member runs between two all-reduces).  A step is not
 # linear in the rows: ~0.15 ms of it is fixed (kernel ramp-up / drain of ~16 launches), which is what makes row-sharding cost
 # GPU time -- three 46,421-row shards take 3 x 0.91 = 2.7 ms where the whole 139,264-row volume takes 2.40.

@@ -50,14 +50,14 @@ def test_gang_sharded_plan_properties():
 
 
 def test_measured_step_time_model_and_the_eight_rank_plan():
-    """dist.StepTimeModel carries the step times MEASURED on one MI355X (profiles/r04_step_time_table.json): the planner prices
+    """dist.StepTimeModel carries the step times MEASURED on one MI355X (profiles/r05_step_time_table.json): the planner prices
     whole volumes and row shards with it.  A step is not linear in the rows (three 46,421-row shards cost more GPU time than the
     139,264-row volume they came from), so the 8-rank plan of the reference's 11 patients is worth ~7.2x, not the 7.56x the
     linear model of round 2 promised; whole-volume packing stays at ~6.0x."""
     import json
     import os
     m = inr_dist.StepTimeModel()
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_step_time_table.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_step_time_table.json")
     measured = {r["rows"]: r for r in json.load(open(path))["table"]}
     for rows in (4096, 69632, 139264, 524288):                       # the embedded table IS the tracked measurement
         assert m.step_ms(rows) == pytest.approx(measured[rows]["fused_ms_per_step"], rel=2e-3)

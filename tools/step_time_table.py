@@ -4,7 +4,7 @@ whole volumes (z = 24 / 28 / 34: 98,304 / 114,688 / 139,264 rows), the row shard
 over 3 or 2 ranks: 46,421 / 46,422 / 69,632 rows), small fits (4,096 / 16,384) and the synthetic 128^3 (524,288).
 `fused` = SirenFitter.step (inr_siren_fit: the whole-volume path), `sharded` = ShardedSirenFitter.step with a world of one
 (inr_siren_loss_grad + inr_adam_step + loss copy per step, no all-reduce: what a gang member runs between collectives).
-Writes JSON (default profiles/r04_step_time_table.json); mri-super-resolution_amd/dist.py carries a copy as its default
+Writes JSON (default profiles/r05_step_time_table.json); mri-super-resolution_amd/dist.py carries a copy as its default
 cost model.   python tools/step_time_table.py [out.json]
 """
 import json
@@ -35,7 +35,7 @@ def measure(fitter, x, t, steps, reps=3):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_step_time_table.json")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_step_time_table.json")
     table = []
     for n in ROWS:
         g = torch.Generator(device="cuda").manual_seed(n)
