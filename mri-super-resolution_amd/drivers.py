@@ -427,12 +427,14 @@ class FitError(RuntimeError):
 
 
 def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding: bool = True, stats: Optional[dict] = None,
-                fit_fn=None, requeue: bool = True, concurrent: int = 1, errors: str = "raise", **fit_kwargs) -> List[Dict[str, float]]:
+                fit_fn=None, requeue: bool = True, concurrent: int = 1, errors: str = "raise", plan: Optional[dict] = None,
+                **fit_kwargs) -> List[Dict[str, float]]:
     """Fits every volume once over the ranks of the current process group and returns the gathered per-fit metric
     records on every rank (one RCCL all_gather).  Schedule: ``plan_volumes`` / ``dist.plan_fits`` -- the volumes that do not
     fill a whole round are fitted first, each row-sharded over its own group of ranks, the rest are packed whole (LPT);
     ``allow_sharding=False`` is plain LPT packing (no collective on the data path at all).  ``stats`` (a dict) receives the
-    plan and this rank's busy seconds.
+    plan and this rank's busy seconds.  ``plan``: a schedule of ``dist.plan_fits`` form (``{"gangs": [(job, ranks), ...], "whole": [[job,
+    ...] per rank]}``) to follow instead of the one ``plan_volumes`` would price -- every rank must pass the same one.
 
     Failure handling (the job list is idempotent -- one record per fit).  Every record carries ``status``:
     FIT_OK, FIT_RESEEDED (the fit diverged or collapsed and a re-seeded run was healthy: ``fit_volume``), FIT_FAILED (unhealthy
@@ -455,7 +457,12 @@ def run_volumes(volumes: Sequence[np.ndarray], steps: int = 2500, allow_sharding
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     fit = fit_fn or fit_volume
-    plan = plan_volumes(volumes, steps, world, allow_sharding, **fit_kwargs)
+    if plan is None:
+        plan = plan_volumes(volumes, steps, world, allow_sharding, **fit_kwargs)
+    else:
+        jobs = sorted([j for j, _ in plan["gangs"]] + [j for w in plan["whole"] for j in w])
+        if jobs != list(range(len(volumes))) or len(plan["whole"]) != world:
+            raise ValueError("plan must place every volume exactly once and list the whole-volume jobs of every rank")
     local = []
     t_start = time.perf_counter()
     nan = float("nan")

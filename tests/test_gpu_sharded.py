@@ -138,16 +138,38 @@ def _volumes():
             for z in (2, 5, 2)]
 
 
+def _sharding_plan(world=2):
+    """The schedule that row-shards the 5-slice volume over both ranks.  (`run_volumes` prices its own plan with the measured step-time
+    model, under which sharding a 600-row fit never pays -- through round 4 these tests therefore ran three WHOLE fits and exercised no
+    sharded one, which is how a failure of every multi-step sharded fit of a hidden-64 network stayed hidden: the plan is handed in.)"""
+    from mri_super_resolution_amd import dist as inr_dist
+    vols = _volumes()
+    costs = [float(v.shape[0] // 2 * (v.shape[1] // 2) * v.shape[2]) * 40 for v in vols]
+    return inr_dist.plan_fits(costs, world)
+
+
 def _run_volumes_worker(rank, world, seed):
     from mri_super_resolution_amd import drivers
+    from mri_super_resolution_amd import ops
+    calls = []
+    orig = ops.siren_loss_grad
+
+    def counting(*a, **k):
+        calls.append(1)
+        return orig(*a, **k)
+
+    ops.siren_loss_grad = counting               # (the sharded step's entry point: proof that a row-sharded fit really ran)
     if seed is None:
         # seed=None follows superresDWI.py:105-118 (draws from the GLOBAL numpy / torch generators).  The test's worker
         # processes are fresh: give every rank its own, DIFFERENT, reproducible generator state, so that "the ranks drew
         # different numbers" is exercised on every run and the run is the same on every box.
         np.random.seed(100 + rank)
         torch.manual_seed(100 + rank)
-    return drivers.run_volumes(_volumes(), steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=seed,
-                               chunk_steps=10)
+    stats = {}
+    recs = drivers.run_volumes(_volumes(), steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=seed,
+                               chunk_steps=10, plan=_sharding_plan(world), stats=stats)
+    assert stats["plan"]["gangs"] == [(1, [0, 1])] and len(calls) == 40, (stats["plan"], len(calls))
+    return recs
 
 
 def test_run_volumes_with_a_row_sharded_fit():
@@ -157,7 +179,7 @@ def test_run_volumes_with_a_row_sharded_fit():
     from mri_super_resolution_amd import drivers
     vols = _volumes()
     costs = [float(v.shape[0] // 2 * (v.shape[1] // 2) * v.shape[2]) * 40 for v in vols]
-    plan = inr_dist.plan_fits(costs, 2)
+    plan = _sharding_plan(2)
     assert plan["gangs"] == [(1, [0, 1])] and sorted(j for w in plan["whole"] for j in w) == [0, 2]
     want = [drivers.fit_volume(v, steps=40, hidden_features=64, hidden_layers=1, mapping_size=16, seed=0, chunk_steps=10,
                                return_recon=False) for v in vols]
