@@ -435,7 +435,8 @@ int  inr_prof_read(int kernel_class, int64_t* launches, double* total_ms);
  * inference takes the gate-ahead form of key 24 = 2 (600,000 default: four 128 x 128 x 9 stacks); key 27 = 1 sends the K-contiguous
  * GEMMs of 512 output columns to the row-owning kernel (a block owns 128 rows x all 512 columns, epilogue in line; 0 = default: measured
  * slower, bit-identical) when they have at least key-28 (default 1024) row panels; key 29 = most 128 x 256 tiles (per 256 CUs; default 192) of a launch that
- * still takes the 64 x 128 tiles of gemm_hp_nt_kernel;
+ * still takes the 64 x 128 tiles of gemm_hp_nt_kernel; key 30 = 0 keeps the head step a kernel of its own (1, default: from key-31 = 768
+ * row panels on it rides in the epilogue of the last sine layer, gemm_hp_row_kernel<HPE_HEAD>);
  * keys 8/9 = time-stamp selection of diagnostic builds.
  * PROCESS-GLOBAL and diagnostic only (see "threading" at the top of this file). */
 int inr_debug_set(int key, int value);     /* INR_E_INVALID for an unknown key or a value outside the key's range */

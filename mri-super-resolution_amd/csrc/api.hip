@@ -77,6 +77,12 @@ int h3_weight_split(const float* const* W, const int* out_f, const int* in_f, in
 int param_grad_splits(int64_t n, int in_f, int out_f);
 // pre-split (HL32) path: gemm_hp.inc
 bool hp_head_ok(int hidden);
+bool hp_row_head_ok(int64_t n, int hidden, int in_f);
+int hp_row_head_rows(int64_t n);
+int hp_sine_forward_head(char* dz_hl, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f, int out_f, float omega,
+                         HpScale sa, HpScale sb, HpScale dz_so, const float* head_w, const float* head_b, const float* target,
+                         const float* weight, int64_t count_total, float* slab_b, float* slab_w, float* part_loss, float* part_g,
+                         unsigned* amax_out, hipStream_t stream);
 int gemm_build_flags();
 size_t hp_prep_part_bytes();
 int hp_weight_prep(const float* const* W, const int* out_f, const int* in_f, int layers, char* planes, unsigned* slots,
@@ -103,6 +109,7 @@ extern tune_int g_rams_epi_fuse;       // key 24 (rams.hip)
 extern tune_int g_reduce_onepass;      // key 25 (kernels.hip)
 extern tune_int g_rams_pregate_min_vox;   // key 26 (rams.hip)
 extern tune_int g_hp_narrow_max_tiles;   // key 29 (gemm_f32.hip)
+extern tune_int g_hp_row_head, g_hp_row_head_min_tiles;   // keys 30, 31 (gemm_f32.hip: the head step fused into the last sine layer)
 extern tune_int g_hp_row, g_hp_row_min_tiles;   // keys 27, 28 (gemm_f32.hip: the row-owning 128 x 512 kernel)
 extern tune_int g_hp_head_min_rows;   // key 21 (gemm_f32.hip)
 int hp_input_grad_max_rows(int64_t n);
@@ -814,7 +821,10 @@ struct HpSlabPlan {
 static HpSlabPlan hp_slab_plan(const Layout& L, int64_t n) {
     HpSlabPlan p;
     const int S = L.n_sine, H = L.fan_in[S];
-    const int64_t hb = hp_head_blocks(n);
+    // rows of the head's slabs: one per block of hp_head_step_kernel, or two per 128-row panel when the head step rides in the last sine
+    // layer's epilogue (hp_sine_forward_head) -- the plan reserves for whichever is more
+    int64_t hb = hp_head_blocks(n);
+    if (hp_row_head_rows(n) > hb) hb = hp_row_head_rows(n);
     size_t off = 0;
     auto add = [&](long long len, int rows) {
         HpSlabPlan::Seg sg;
@@ -957,11 +967,13 @@ tune_int g_hp_merge_blocks{256};  // key 22: block count the merged parameter-gr
 // here: every producer leaves its slab rows in `slabs` and `fin` describes them (the caller finishes with launch_finalize).
 // forward of the sine layers (stash kept for the backward pass); z_head: the last layer stashes z + b only (HPE_Z)
 static int hp_forward_pass(const inr_siren_desc_t* d, const Layout& L, const float* params, std::vector<float*>& act,
-                           std::vector<float*>& dact, const char* xhl, int64_t n, hipStream_t st, const H3Ctx& ctx, bool z_head) {
+                           std::vector<float*>& dact, const char* xhl, int64_t n, hipStream_t st, const H3Ctx& ctx, bool z_head,
+                           bool skip_last = false) {
+    // skip_last: the last sine layer runs inside hp_backward_pass with the head step in its epilogue (hp_sine_forward_head)
     const HpNet net{&ctx, &L};
     const int head = L.n_sine;
     auto act_hl = [&](int l) -> const char* { return l == 0 ? xhl : reinterpret_cast<const char*>(act[l]); };
-    for (int l = 0; l < L.n_sine; ++l) {
+    for (int l = 0; l < L.n_sine - (skip_last ? 1 : 0); ++l) {
         const float omega = (l == 0) ? d->first_omega : d->hidden_omega;
         if (int rc = hp_sine_forward(reinterpret_cast<char*>(act[l + 1]), dact[l], act_hl(l), net.w_hl(l), params + L.b_off[l], n,
                                      L.fan_in[l], L.fan_out[l], omega, net.act_scale(l), net.w_scale(l), 0, st,
@@ -977,7 +989,7 @@ static int hp_forward_pass(const inr_siren_desc_t* d, const Layout& L, const flo
 static int hp_backward_pass(const inr_siren_desc_t* d, const Layout& L, const float* params, float* grads,
                             std::vector<float*>& act, std::vector<float*>& dact, const char* xhl, float* slabs,
                             const float* target, const float* weight, const float* g_ext, int64_t n, int64_t count_total,
-                            float* loss_dst, hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin, bool z_head) {
+                            float* loss_dst, hipStream_t st, const H3Ctx& ctx, FinalizeJob& fin, bool z_head, bool fuse_head = false) {
     const int H = d->hidden_features, head = L.n_sine;
     const HpNet net{&ctx, &L};
     const HpSlabPlan plan = hp_slab_plan(L, n);
@@ -1010,7 +1022,21 @@ static int hp_backward_pass(const inr_siren_desc_t* d, const Layout& L, const fl
         }
         return s;
     };
-    {
+    if (fuse_head) {   // the last sine layer with the head step in its epilogue: no z round trip, no head step kernel (gemm_hp_row.inc, HPE_HEAD)
+        const int rows = hp_row_head_rows(n);
+        const int kb = 2 * (head - 1) + 1, kw = 2 * head, kg = 2 * head + 1;   // b_{S-1}, W_head, b_head
+        float* part_loss = slabs + plan.part_loss;
+        if (int rc = hp_sine_forward_head(reinterpret_cast<char*>(dact[head - 1]), act_hl(head - 1), net.w_hl(head - 1),
+                                          params + L.b_off[head - 1], n, L.fan_in[head - 1], H, omega_last, net.act_scale(head - 1),
+                                          net.w_scale(head - 1), dz_scale(head - 1), params + L.w_off[head], params + L.b_off[head],
+                                          target, weight, count_total, const_cast<float*>(fin.seg[kb].slab),
+                                          const_cast<float*>(fin.seg[kw].slab), part_loss, const_cast<float*>(fin.seg[kg].slab),
+                                          ctx.slots + 8 + head - 1, st))
+            return rc;
+        fin.seg[kb].nslabs = fin.seg[kw].nslabs = fin.seg[kg].nslabs = rows;
+        fin.part_loss = part_loss;
+        fin.nparts = rows;
+    } else {
         const int blocks = (int)hp_head_blocks(n);
         const int kb = 2 * (head - 1) + 1, kw = 2 * head, kg = 2 * head + 1;   // b_{S-1}, W_head, b_head
         float* part_loss = slabs + plan.part_loss;
@@ -1080,9 +1106,11 @@ static int fit_forward_backward_hp(const inr_siren_desc_t* d, const Layout& L, c
     // the output of the LAST sine layer feeds nothing but the head: that layer stashes z + b only (one fp32 matrix instead
     // of act + omega cos) and the head step forms sin / cos itself -- 2.1 GB less HBM traffic per step at N = 524,288
     const bool z_head = hp_z_stash_ok(L.fan_in[head - 1]);
-    if (int rc = hp_forward_pass(d, L, params, act, dact, xhl, n, st, ctx, z_head)) return rc;
+    // ... and from 768 row panels (98,304 rows) on the head step rides in that layer's epilogue (a block of gemm_hp_row_kernel owns whole rows)
+    const bool fuse_head = z_head && hp_row_head_ok(n, d->hidden_features, L.fan_in[head - 1]);
+    if (int rc = hp_forward_pass(d, L, params, act, dact, xhl, n, st, ctx, z_head, fuse_head)) return rc;
     return hp_backward_pass(d, L, params, grads, act, dact, xhl, slabs, target, weight, nullptr, n, count_total, loss_dst, st, ctx,
-                            fin, z_head);
+                            fin, z_head, fuse_head);
 }
 
 // per call: scales of the network input and of the targets, HL32 image of x
@@ -1735,6 +1763,7 @@ const DebugKey* debug_table(int* count) {
         {26, &g_rams_pregate_min_vox, 600000, 0, 1 << 30},
         {27, &g_hp_row, 0, 0, 1},        {28, &g_hp_row_min_tiles, 1024, 1, 1 << 30},
         {29, &g_hp_narrow_max_tiles, 192, 0, 1 << 30},
+        {30, &g_hp_row_head, 1, 0, 1},   {31, &g_hp_row_head_min_tiles, 768, 1, 1 << 30},
     };
     *count = (int)(sizeof(table) / sizeof(table[0]));
     return table;

@@ -1308,6 +1308,43 @@ int hp_sine_forward(char* act_hl, float* dact, const char* x_hl, const char* W_h
     return 0;
 }
 
+// The last sine layer of a fit step with the head step in its epilogue (gemm_hp_row_kernel<HPE_HEAD>, gemm_hp_row.inc): dz_L (HL32, scale
+// `dz_so`) over the bytes of `dact`, per 64-row half panel one row of slab_b (column sums of dz_L = the layer's bias gradient), slab_w
+// (sum_n g_n sin(.) = the head's weight gradient), part_loss and part_g; max|dz_L| into `amax_out`.  2 * ceil(n / 128) slab rows.
+tune_int g_hp_row_head{1};              // inr_debug_set(30, 0): never (the z-only layer + hp_head_step_kernel instead)
+tune_int g_hp_row_head_min_tiles{768};  // inr_debug_set(31, v): fewest 128-row panels of a launch that takes the fused form (98,304 rows:
+                                        // measured break-even at ~65-70 k rows, -1.6 % at 98 k, -2.2 % at 139 k, -2.4 % at 524 k: profiles/r05_head_fuse_sweep.txt)
+bool hp_row_head_ok(int64_t n, int hidden, int in_f) {
+    return g_hp_row_head && g_hp_persistent == 2 && hidden == HR_BN && (in_f == 512 || in_f == 256) &&
+           (n + HP_BM - 1) / HP_BM >= g_hp_row_head_min_tiles && (n + HP_BM - 1) / HP_BM < (1ll << 30);
+}
+int hp_row_head_rows(int64_t n) { return 2 * (int)((n + HP_BM - 1) / HP_BM); }
+int hp_sine_forward_head(char* dz_hl, const char* x_hl, const char* W_hl, const float* bias, int64_t n, int in_f, int out_f, float omega,
+                         HpScale sa, HpScale sb, HpScale dz_so, const float* head_w, const float* head_b, const float* target,
+                         const float* weight, int64_t count_total, float* slab_b, float* slab_w, float* part_loss, float* part_g,
+                         unsigned* amax_out, hipStream_t stream) {
+    INR_REQUIRE(hp_row_head_ok(n, out_f, in_f), INR_E_INVALID, "hp_sine_forward_head: shape not served (n = %lld, %d -> %d)", (long long)n, in_f, out_f);
+    HpParams p{};
+    p.A = x_hl; p.B = W_hl;
+    p.M = (int)n; p.N = out_f; p.K = in_f;
+    p.pitchA = (long long)in_f * 4; p.pitchB = (long long)in_f * 4;
+    p.a_rows = n; p.b_rows = out_f;
+    p.sa = sa; p.sb = sb; p.so = dz_so;
+    p.C_hl = dz_hl; p.bias = bias; p.omega = omega;
+    p.k_per_split = in_f; p.stagger = g_hp_stagger; p.splits = 1;
+    p.tiles_m = (int)((n + HP_BM - 1) / HP_BM); p.tiles_n = 1;
+    p.colsum = slab_b; p.slab_w = slab_w; p.part_loss = part_loss; p.part_g = part_g; p.amax_out = amax_out;
+    p.head_w = head_w; p.head_b = head_b; p.target = target; p.tweight = weight;
+    p.inv_count = (float)(1.0 / (double)(count_total > 0 ? count_total : n));
+    p.stamps = hp_stamp_target(KC_GEMM_FWD);
+    ProfScope ps(KC_GEMM_FWD, stream);
+    const dim3 rgrid((unsigned)(p.tiles_m < hp_num_cus() ? p.tiles_m : hp_num_cus())), block(HP_NTH);
+    hipLaunchKernelGGL((gemm_hp_row_kernel<HPE_HEAD>), rgrid, block, 0, stream, p);
+    INR_LAUNCH_CHECK();
+    count_launch(LF_HP_ROW);
+    return 0;
+}
+
 // rows of column sums an input-grad launch may write (two per 64-row tile is the finest any of the kernels goes)
 int hp_input_grad_max_rows(int64_t n) { return 2 * (int)((n + 63) / 64); }
 

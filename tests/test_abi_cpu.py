@@ -183,7 +183,7 @@ def test_debug_switches_are_validated_readable_and_resettable():
     assert lib.inr_debug_set(24, 3) == _lib.INR_E_INVALID and lib.inr_debug_set(23, 5000) == _lib.INR_E_INVALID
     assert lib.inr_debug_reset() == 0
     for key, default in ((0, 0), (1, 1), (2, 1), (3, 1), (5, 1), (6, 1), (7, 1), (10, 2), (11, 0), (12, 1), (13, 0), (14, 2),
-                         (15, 42), (16, 1), (17, 0), (18, 1), (19, 0), (20, 1), (21, 16), (22, 256), (23, 0), (24, 2), (25, 1), (26, 600000), (27, 0), (28, 1024), (29, 192)):
+                         (15, 42), (16, 1), (17, 0), (18, 1), (19, 0), (20, 1), (21, 16), (22, 256), (23, 0), (24, 2), (25, 1), (26, 600000), (27, 0), (28, 1024), (29, 192), (30, 1), (31, 768)):
         assert lib.inr_debug_get(key, ctypes.byref(v)) == 0 and v.value == default, (key, v.value)
     n = ctypes.c_int64(-1)
     assert lib.inr_launch_counts_reset() == 0

@@ -481,3 +481,62 @@ def test_row_owning_kernel_is_bit_identical_to_the_deferred_epilogue_kernel(fin,
     assert c1["hp_row"] == want_row, c1
     assert np.array_equal(l0, l1) and np.array_equal(f0, f1) and np.array_equal(y0, y1)
     assert np.isfinite(l1).all() and l1[-1] < l1[0]
+
+
+# ------------------------------------------------------------------ the head step fused into the last sine layer (round 5) ---------
+@pytest.mark.parametrize("fin,layers,n,weighted", [(256, 2, 128 * 5 + 77, True), (512, 0, 128 * 3, False), (256, 3, 128 * 20 + 1, False),
+                                                   (64, 1, 1000, True)])
+def test_fused_head_epilogue_vs_float64_and_vs_the_head_step_kernel(fin, layers, n, weighted):
+    """`gemm_hp_row_kernel<HPE_HEAD>` (csrc/gemm_hp_row.inc): the last sine layer's block owns whole rows, so the head -- y, residual,
+    dL/dy, dz_L = g w omega cos, the bias / head-weight gradient slabs, the loss -- is formed in its epilogue: no z round trip, no head
+    step kernel.  Debug key 31 = 1 lets any row count take it (default: from 768 row panels = 98,304 rows on).  Against the float64 oracle (tiers
+    T1 / T2, as every other family here) and against the unfused path (key 30 = 0): same arithmetic per element, other summation orders."""
+    net, ref = make_pair(fin, 512, layers, seed=fin + layers + n)
+    net.cuda()
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, fin, generator=g) * 2 - 1
+    t = torch.rand(n, generator=g) * 2 - 1
+    w = ((torch.rand(n, generator=g) > 0.25).float() * (0.5 + torch.rand(n, generator=g))) if weighted else None
+    want_loss, want_g, want_y = oracle_loss_grads(ref, x, t, w)
+    xd, td, wd = x.cuda(), t.cuda(), None if w is None else w.cuda()
+    with ops.debug_switch(31, 1):
+        ops.launch_counts_reset()
+        loss, got_g, got_y = fused_loss_grads(net, xd, td, wd)
+        counts = ops.launch_counts()
+    assert counts["hp_row"] == 1 and counts["hp_rc"] == layers + 1, counts          # the last sine layer of the loss_grad call, nothing else
+    assert abs(loss - want_loss) <= T2 * abs(want_loss)
+    for k, (a, b) in enumerate(zip(got_g, want_g)):
+        assert O.rel_l2(a, b) < T2, (k, O.rel_l2(a, b))
+    with ops.debug_switch(30, 0):
+        ops.launch_counts_reset()
+        loss0, got0, _ = fused_loss_grads(net, xd, td, wd)
+        assert ops.launch_counts()["hp_row"] == 0
+    assert abs(loss - loss0) <= 2e-6 * abs(loss0)
+    for k, (a, b) in enumerate(zip(got_g, got0)):
+        assert O.rel_l2(a, b) < 2e-6, (k, O.rel_l2(a, b))
+
+
+def test_fused_head_fit_trajectory_and_cycling_targets():
+    """Thirty fused fit steps (inr_siren_fit) and a cycling-acquisition call (inr_siren_fit_cycle: target and weight image change every
+    step) with the head in the last layer's epilogue against the same calls through the head step kernel: tier T3 (1e-4) on the weights,
+    per-step losses within 1e-5."""
+    n, fin = 128 * 9 + 50, 256
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(n, fin, generator=g) * 2 - 1).cuda()
+    t = torch.rand(n, generator=g).cuda()
+    tg = torch.rand(3, n, generator=g).cuda()
+    wt = torch.rand(3, n, generator=g).cuda()
+    out = {}
+    for fused in (1, 0):
+        with ops.debug_switch(30, fused), ops.debug_switch(31, 1):
+            torch.manual_seed(0)
+            f = inr.SirenFitter(inr.Siren(fin, 512, 2, 1).cuda(), lr=1e-4)
+            ops.launch_counts_reset()
+            l1 = f.step(x, t, 30)
+            l2 = f.step_cycle(x, tg, 7, wt, first_acq=1)
+            torch.cuda.synchronize()
+            out[fused] = (host(l1), host(l2), host(f.flat), ops.launch_counts()["hp_row"])
+    assert out[1][3] == 37 and out[0][3] == 0
+    assert np.allclose(out[1][0], out[0][0], rtol=1e-5) and np.allclose(out[1][1], out[0][1], rtol=1e-5)
+    assert O.rel_l2(out[1][2], out[0][2]) < 1e-4
+    assert out[1][0][-1] < out[1][0][0]
