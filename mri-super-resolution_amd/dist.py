@@ -72,12 +72,13 @@ def _split_ranks(world_size: int, weights: Sequence[float]) -> List[List[int]]:
 # tools/step_time_table.py -> profiles/r05_step_time_table.json; tests/test_dist_cpu.py holds this table to that file).  `fused` = inr_siren_fit (a whole volume on one rank),
 # `sharded` = inr_siren_loss_grad + inr_adam_step per step (what a gang member runs between two all-reduces).  A step is not
 # linear in the rows: ~0.15 ms of it is fixed (kernel ramp-up / drain of ~16 launches), which is what makes row-sharding cost
-# GPU time -- three 46,421-row shards take 3 x 0.85 = 2.55 ms where the whole 139,264-row volume takes 2.41.
+# GPU time -- three 46,421-row shards take 3 x 0.86 = 2.57 ms where the whole 139,264-row volume takes 2.33 (from 98,304 rows on
+# the head step rides in the last sine layer's epilogue: csrc/gemm_hp_row.inc).
 STEP_TIME_TABLE_MS = (
     # rows, fused, sharded
-    (4096, 0.1903, 0.1926), (16384, 0.4024, 0.4059), (32768, 0.6412, 0.6435), (46421, 0.8480, 0.8510),
-    (65536, 1.1460, 1.1494), (69632, 1.2640, 1.2662), (98304, 1.6851, 1.6855), (114688, 1.9333, 1.9397),
-    (139264, 2.4131, 2.4159), (262144, 4.3834, 4.3829), (524288, 8.6837, 8.6788),
+    (4096, 0.1844, 0.1897), (16384, 0.4058, 0.4086), (32768, 0.6574, 0.6609), (46421, 0.8570, 0.8601),
+    (65536, 1.1554, 1.1564), (69632, 1.2672, 1.2709), (98304, 1.6387, 1.6408), (114688, 1.9076, 1.9075),
+    (139264, 2.3296, 2.3376), (262144, 4.2729, 4.2601), (524288, 8.4600, 8.4684),
 )
 GRADIENT_BYTES = 3_682_320          # flat fp32 gradient of Siren(256,512,3,1) + the loss slot: one all-reduce per step
 
