@@ -540,3 +540,30 @@ def test_fused_head_fit_trajectory_and_cycling_targets():
     assert np.allclose(out[1][0], out[0][0], rtol=1e-5) and np.allclose(out[1][1], out[0][1], rtol=1e-5)
     assert O.rel_l2(out[1][2], out[0][2]) < 1e-4
     assert out[1][0][-1] < out[1][0][0]
+
+
+def test_fused_head_as_a_row_shard_and_run_to_run_bits():
+    """The fused-head layer inside `inr_siren_loss_grad` with `count_total` = the GLOBAL row count (what a row-sharded fit passes: the mean
+    is taken over all shards) against the head-step path, and two runs of the same call bit for bit (fixed-order slabs, no float atomics)."""
+    n, fin = 128 * 7 + 19, 256
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, fin, generator=g) * 2 - 1).cuda()
+    t = torch.rand(n, generator=g).cuda()
+    w = (torch.rand(n, generator=g) + 0.25).cuda()
+    torch.manual_seed(3)
+    net = inr.Siren(fin, 512, 1, 1).cuda()
+    desc, flat = inr.flat_parameters(net)
+
+    def run(fused):
+        with ops.debug_switch(30, fused), ops.debug_switch(31, 1):
+            grads, loss = torch.zeros_like(flat), torch.zeros(1, device="cuda")
+            ops.launch_counts_reset()
+            ops.siren_loss_grad(desc, flat, grads, x, t, w, 3 * n, loss)
+            return host(grads), float(loss), ops.launch_counts()["hp_row"]
+
+    g1, l1, c1 = run(1)
+    g2, l2, c2 = run(1)
+    g0, l0, c0 = run(0)
+    assert c1 == c2 == 1 and c0 == 0
+    assert np.array_equal(g1, g2) and l1 == l2
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and O.rel_l2(g1, g0) < 2e-6
