@@ -519,7 +519,7 @@ def test_fused_head_epilogue_vs_float64_and_vs_the_head_step_kernel(fin, layers,
 def test_fused_head_fit_trajectory_and_cycling_targets():
     """Thirty fused fit steps (inr_siren_fit) and a cycling-acquisition call (inr_siren_fit_cycle: target and weight image change every
     step) with the head in the last layer's epilogue against the same calls through the head step kernel: tier T3 (1e-4) on the weights,
-    per-step losses within 1e-5."""
+    per-step losses within 1e-4 of each other and of the torch-CPU port."""
     n, fin = 128 * 9 + 50, 256
     g = torch.Generator().manual_seed(5)
     x = (torch.rand(n, fin, generator=g) * 2 - 1).cuda()
@@ -537,9 +537,15 @@ def test_fused_head_fit_trajectory_and_cycling_targets():
             torch.cuda.synchronize()
             out[fused] = (host(l1), host(l2), host(f.flat), ops.launch_counts()["hp_row"])
     assert out[1][3] == 37 and out[0][3] == 0
-    assert np.allclose(out[1][0], out[0][0], rtol=1e-5) and np.allclose(out[1][1], out[0][1], rtol=1e-5)
+    # tier T3 (north_star: trajectories of <= 50 steps within 1e-4): against each other and, the 30 plain steps, against the torch-CPU
+    # port of the reference loop (the trajectory is in Adam's oscillating regime by step 20: losses 0.0046 -> 0.0058 -> 0.0027 -> ...,
+    # where weights that agree to 4e-7 give losses that agree to 1e-5)
+    assert np.allclose(out[1][0], out[0][0], rtol=1e-4) and np.allclose(out[1][1], out[0][1], rtol=1e-4)
     assert O.rel_l2(out[1][2], out[0][2]) < 1e-4
     assert out[1][0][-1] < out[1][0][0]
+    torch.manual_seed(0)
+    port_losses, _ = P.port_fit(P.PortSiren(fin, 512, 2, 1), x.cpu(), t.cpu().reshape(-1, 1), 30, lr=1e-4)
+    assert np.allclose(out[1][0], port_losses, rtol=1e-4) and np.allclose(out[0][0], port_losses, rtol=1e-4)
 
 
 def test_fused_head_as_a_row_shard_and_run_to_run_bits():
